@@ -1,0 +1,444 @@
+// CSR neighbour aggregation for gfx950: one 64-lane wave per destination row, the
+// lanes spanning the feature width so that every gathered source row is one fully
+// coalesced 16-B-per-lane load.  Column ids / edge weights of a row are fetched
+// 64 at a time with one coalesced load and broadcast with v_readlane, which makes
+// every gather address "scalar base + lane offset".  Rows longer than
+// kHubThreshold are cut into kHubSlice-edge slices that other waves (on other
+// CUs) pick up in a second launch and combine with fp32 atomics, because a single
+// CU cannot stream a 10^4-edge row fast enough (power-law graphs).
+//
+// HBM roofline: the kernel moves E*(4+4) index/weight bytes, (B+1)*4 row pointers,
+// one read of every distinct source row (width*4 B each) and one write of every
+// destination row; flops are 2*E*width, i.e. ~0.5 flop per gathered byte.
+#include "common.h"
+
+#include <climits>
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace incagg {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kHubThreshold = 512;  // rows with more edges are sliced
+constexpr int kHubSlice = 256;      // edges per slice
+constexpr int kQueueCap = 1 << 20;  // slices per call that the queue can hold
+
+template <int VEC> struct VT;
+template <> struct VT<1> { using type = float; };
+template <> struct VT<4> { using type = f4; };
+
+template <int VEC>
+__device__ __forceinline__ typename VT<VEC>::type ldv(const float *p) {
+  return *reinterpret_cast<const typename VT<VEC>::type *>(p);
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float *p, typename VT<VEC>::type v) {
+  *reinterpret_cast<typename VT<VEC>::type *>(p) = v;
+}
+
+struct SpmmArgs {
+  const int *rowptr;
+  const int *col;
+  const float *val;
+  const float *x;
+  long long ldx;
+  const float *m_in;
+  long long ldin;
+  const float *m_ag;
+  long long ldag;
+  const float *add;
+  long long ldadd;
+  float *y;
+  long long ldy;
+  int n_rows;
+  int n_cols;
+  int width;
+  int mean;
+  float scale;
+  float add_scale;
+  int hub_threshold;
+  int2 *queue;
+  int *q_count;
+  int *q_count_next;
+  int q_cap;
+  int *err;
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// U edges starting at local edge j of the current 64-edge window: all gathers are
+// issued before the first FMA so that U (or 2U) row loads are in flight per wave.
+template <int VEC, int CH, bool INCAGG, int U>
+__device__ __forceinline__ void edge_step(const SpmmArgs &a, int my_c, float my_v, int j,
+                                          const int (&off)[CH],
+                                          typename VT<VEC>::type (&acc)[CH]) {
+  using V = typename VT<VEC>::type;
+  V xv[U][CH];
+  V mv[U][CH];
+  float w[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int c = __builtin_amdgcn_readlane(my_c, j + u);
+    w[u] = readlane_f(my_v, j + u);
+    const float *xr = a.x + (size_t)c * a.ldx;
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) xv[u][ch] = ldv<VEC>(xr + off[ch]);
+    if (INCAGG) {
+      const float *mr = a.m_in + (size_t)c * a.ldin;
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++) mv[u][ch] = ldv<VEC>(mr + off[ch]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+      if (INCAGG)
+        acc[ch] += w[u] * (xv[u][ch] - mv[u][ch]);
+      else
+        acc[ch] += w[u] * xv[u][ch];
+    }
+  }
+}
+
+// acc += sum over edges [rs, re) of one row.  rs/re are wave-uniform.
+template <int VEC, int CH, bool INCAGG>
+__device__ __forceinline__ void accumulate_edges(const SpmmArgs &a, int rs, int re, int lane,
+                                                 const int (&off)[CH],
+                                                 typename VT<VEC>::type (&acc)[CH]) {
+  constexpr int UMAX = INCAGG ? 4 : 8;
+  for (int e0 = rs; e0 < re; e0 += kWave) {
+    const int cnt = min(kWave, re - e0);
+    int my_c = 0;
+    float my_v = 0.f;
+    if (lane < cnt) {
+      my_c = a.col[e0 + lane];
+      my_v = a.val ? a.val[e0 + lane] : 1.0f;
+      if ((unsigned)my_c >= (unsigned)a.n_cols) {  // never fault on a bad id
+        *a.err = 1;
+        my_c = 0;
+        my_v = 0.f;
+      }
+    }
+    int j = 0;
+    for (; j + UMAX <= cnt; j += UMAX) edge_step<VEC, CH, INCAGG, UMAX>(a, my_c, my_v, j, off, acc);
+    if (UMAX > 4 && j + 4 <= cnt) {
+      edge_step<VEC, CH, INCAGG, 4>(a, my_c, my_v, j, off, acc);
+      j += 4;
+    }
+    if (j + 2 <= cnt) {
+      edge_step<VEC, CH, INCAGG, 2>(a, my_c, my_v, j, off, acc);
+      j += 2;
+    }
+    if (j < cnt) edge_step<VEC, CH, INCAGG, 1>(a, my_c, my_v, j, off, acc);
+  }
+}
+
+// Lanes whose columns lie beyond `width` read column 0 instead (a valid address,
+// result discarded), which keeps the gather loop free of per-lane branches.
+template <int VEC, int CH>
+__device__ __forceinline__ void column_offsets(int lane, int width, int (&off)[CH],
+                                               bool (&live)[CH]) {
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++) {
+    const int c = lane * VEC + ch * kWave * VEC;
+    live[ch] = c < width;
+    off[ch] = live[ch] ? c : 0;
+  }
+}
+
+template <int VEC, int CH, bool INCAGG>
+__device__ __forceinline__ void store_row(const SpmmArgs &a, int row, float s,
+                                          const int (&off)[CH], const bool (&live)[CH],
+                                          const typename VT<VEC>::type (&acc)[CH]) {
+  using V = typename VT<VEC>::type;
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++) {
+    if (!live[ch]) continue;
+    V out = acc[ch] * s;
+    if (INCAGG) out += a.scale * ldv<VEC>(a.m_ag + (size_t)row * a.ldag + off[ch]);
+    if (a.add) out += a.add_scale * ldv<VEC>(a.add + (size_t)row * a.ldadd + off[ch]);
+    stv<VEC>(a.y + (size_t)row * a.ldy + off[ch], out);
+  }
+}
+
+template <int VEC, int CH, bool INCAGG>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const SpmmArgs a) {
+  using V = typename VT<VEC>::type;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  // Blocks b and b + 8 share an XCD (and its L2): give every XCD one contiguous
+  // range of rows, since neighbouring rows of a partition share source rows.
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+  const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int row = lb * kWavesPerBlock + wave;
+  if (row >= a.n_rows) return;
+
+  const int rs = rfl(a.rowptr[row]);
+  const int re = rfl(a.rowptr[row + 1]);
+  const int deg = re - rs;
+
+  int off[CH];
+  bool live[CH];
+  column_offsets<VEC, CH>(lane, a.width, off, live);
+  V acc[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++) acc[ch] = V(0.f);
+
+  if (deg > a.hub_threshold) {
+    const int ns = (deg + kHubSlice - 1) / kHubSlice;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.q_count, ns);
+    base = rfl(base);
+    const bool fits = base + ns <= a.q_cap;
+    for (int k = lane; k < ns && base + k < a.q_cap; k += kWave)
+      a.queue[base + k] = fits ? make_int2(row, k) : make_int2(-1, 0);
+    if (fits) {  // slices add onto this base value in the second launch
+      store_row<VEC, CH, INCAGG>(a, row, 0.f, off, live, acc);
+      return;
+    }
+  }
+  accumulate_edges<VEC, CH, INCAGG>(a, rs, re, lane, off, acc);
+  const float s = a.scale * (a.mean ? 1.0f / (float)max(deg, 1) : 1.0f);
+  store_row<VEC, CH, INCAGG>(a, row, s, off, live, acc);
+}
+
+template <int VEC, int CH, bool INCAGG>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_hub_kernel(const SpmmArgs a) {
+  using V = typename VT<VEC>::type;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int n = min(rfl(*a.q_count), a.q_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.q_count_next = 0;  // for the next call
+  int off[CH];
+  bool live[CH];
+  column_offsets<VEC, CH>(lane, a.width, off, live);
+  const int nw = gridDim.x * kWavesPerBlock;
+  for (int sidx = blockIdx.x * kWavesPerBlock + wave; sidx < n; sidx += nw) {
+    const int2 ent = a.queue[sidx];
+    const int row = rfl(ent.x);
+    if (row < 0) continue;
+    const int k = rfl(ent.y);
+    const int rs0 = rfl(a.rowptr[row]);
+    const int re0 = rfl(a.rowptr[row + 1]);
+    const int rs = rs0 + k * kHubSlice;
+    const int re = min(re0, rs + kHubSlice);
+    V acc[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) acc[ch] = V(0.f);
+    accumulate_edges<VEC, CH, INCAGG>(a, rs, re, lane, off, acc);
+    const float s = a.scale * (a.mean ? 1.0f / (float)max(re0 - rs0, 1) : 1.0f);
+    float *yr = a.y + (size_t)row * a.ldy;
+    if constexpr (VEC == 1) {
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++)
+        if (live[ch]) atomicAdd(yr + off[ch], acc[ch] * s);
+    } else {
+      // Regroup so that each atomic wave-instruction covers 256 contiguous bytes:
+      // lane l adds column 64 t + l, held by lane 16 t + l / 4 in component l % 4.
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int src = 16 * t + (lane >> 2);
+          const float v0 = __shfl(acc[ch].x, src), v1 = __shfl(acc[ch].y, src);
+          const float v2 = __shfl(acc[ch].z, src), v3 = __shfl(acc[ch].w, src);
+          const int sel = lane & 3;
+          const float v = sel == 0 ? v0 : sel == 1 ? v1 : sel == 2 ? v2 : v3;
+          const int c = ch * kWave * VEC + kWave * t + lane;
+          if (c < a.width) atomicAdd(yr + c, v * s);
+        }
+      }
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void rows_sub_kernel(const float *a, long long lda,
+                                                      const float *b, long long ldb,
+                                                      long long n_rows, int width, float *d,
+                                                      long long ldd) {
+  const int per_row = width / VEC;
+  const long long total = n_rows * per_row;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / per_row;
+    const int c = (int)(i - r * per_row) * VEC;
+    stv<VEC>(d + r * ldd + c, ldv<VEC>(a + r * lda + c) - ldv<VEC>(b + r * ldb + c));
+  }
+}
+
+// ---------------------------------------------------------------- host side
+struct HubQueue {
+  int2 *entries = nullptr;
+  int *counters = nullptr;  // two words used alternately; the idle one is zero
+  int parity = 0;
+};
+
+static std::mutex s_queue_mutex;
+static std::map<std::pair<int, hipStream_t>, HubQueue> s_queues;
+
+// The slice queue of (device, stream); created on first use.  Calls on one stream
+// are ordered, so one queue per stream can never be used by two launches at once.
+static int hub_queue_for(hipStream_t stream, HubQueue **out) {
+  int dev = 0;
+  INCAGG_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(s_queue_mutex);
+  HubQueue &q = s_queues[{dev, stream}];
+  if (!q.entries) {
+    INCAGG_HIP_TRY(hipMalloc(&q.entries, sizeof(int2) * (size_t)kQueueCap));
+    hipError_t e = hipMalloc(&q.counters, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(q.counters, 0, 2 * sizeof(int));
+    if (e != hipSuccess) {
+      (void)hipFree(q.entries);
+      q.entries = nullptr;
+      return fail(INCAGG_E_HIP, "hub queue allocation failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = &q;
+  return INCAGG_OK;
+}
+
+template <int VEC, int CH, bool INCAGG>
+static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
+  const bool may_have_hubs = max_row_nnz < 0 || max_row_nnz > kHubThreshold;
+  HubQueue *q = nullptr;
+  if (may_have_hubs) {
+    int rc = hub_queue_for(stream, &q);
+    if (rc) return rc;
+    a.hub_threshold = kHubThreshold;
+    a.queue = q->entries;
+    a.q_count = q->counters + q->parity;
+    a.q_count_next = q->counters + (q->parity ^ 1);
+    a.q_cap = kQueueCap;
+  } else {
+    a.hub_threshold = INT_MAX;
+    a.queue = nullptr;
+    a.q_count = a.q_count_next = nullptr;
+    a.q_cap = 0;
+  }
+  const int blocks = (a.n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, CH, INCAGG>), dim3(blocks), dim3(kWave * kWavesPerBlock),
+                     0, stream, a);
+  INCAGG_HIP_TRY(hipGetLastError());
+  if (may_have_hubs) {
+    hipLaunchKernelGGL((spmm_hub_kernel<VEC, CH, INCAGG>), dim3(2048),
+                       dim3(kWave * kWavesPerBlock), 0, stream, a);
+    INCAGG_HIP_TRY(hipGetLastError());
+    q->parity ^= 1;
+  }
+  return INCAGG_OK;
+}
+
+template <bool INCAGG>
+static int dispatch_spmm(SpmmArgs &a, bool vec4, long long max_row_nnz, hipStream_t stream) {
+  const int w = a.width;
+  if (vec4) {
+    if (w <= 256) return launch_spmm<4, 1, INCAGG>(a, max_row_nnz, stream);
+    if (w <= 512) return launch_spmm<4, 2, INCAGG>(a, max_row_nnz, stream);
+    if (w <= 1024) return launch_spmm<4, 4, INCAGG>(a, max_row_nnz, stream);
+  } else {
+    if (w <= 64) return launch_spmm<1, 1, INCAGG>(a, max_row_nnz, stream);
+    if (w <= 128) return launch_spmm<1, 2, INCAGG>(a, max_row_nnz, stream);
+    if (w <= 256) return launch_spmm<1, 4, INCAGG>(a, max_row_nnz, stream);
+  }
+  return fail(INCAGG_E_INVALID, "width %d unsupported (max 1024 when 16-byte aligned, else 256)", w);
+}
+
+static bool rows_vec4(const float *p, long long ld) { return !p || (aligned16(p) && ld % 4 == 0); }
+
+}  // namespace incagg
+
+using namespace incagg;
+
+static int check_common(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
+                        int64_t n_rows, int64_t n_cols, int64_t width, int reduce,
+                        const float *add, int64_t ldadd, float *y, int64_t ldy) {
+  INCAGG_REQUIRE(n_rows >= 0 && n_cols >= 0 && width >= 0, "negative size");
+  INCAGG_REQUIRE(n_rows < INT_MAX - 8 && n_cols < INT_MAX && width <= 1024,
+                 "size out of range (rows %lld cols %lld width %lld)", (long long)n_rows,
+                 (long long)n_cols, (long long)width);
+  INCAGG_REQUIRE(reduce == INCAGG_REDUCE_SUM || reduce == INCAGG_REDUCE_MEAN, "bad reduce %d", reduce);
+  if (n_rows == 0 || width == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(rowptr && y, "null rowptr or output");
+  INCAGG_REQUIRE(ldy >= width, "ldy %lld < width %lld", (long long)ldy, (long long)width);
+  INCAGG_REQUIRE(!x || ldx >= width, "ldx %lld < width %lld", (long long)ldx, (long long)width);
+  INCAGG_REQUIRE(!add || ldadd >= width, "ldadd %lld < width %lld", (long long)ldadd, (long long)width);
+  INCAGG_REQUIRE(n_cols == 0 || (x && col), "null x or col with n_cols > 0");
+  INCAGG_REQUIRE((const void *)x != (const void *)y, "y must not alias x");
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                                   const float *x, int64_t ldx, int64_t n_rows, int64_t n_cols,
+                                   int64_t width, int reduce, float scale, const float *add,
+                                   int64_t ldadd, float add_scale, int64_t max_row_nnz, float *y,
+                                   int64_t ldy, void *stream) {
+  int rc = check_common(rowptr, col, x, ldx, n_rows, n_cols, width, reduce, add, ldadd, y, ldy);
+  if (rc) return rc;
+  if (n_rows == 0 || width == 0) return INCAGG_OK;
+  SpmmArgs a{};
+  a.rowptr = rowptr; a.col = col; a.val = val; a.x = x; a.ldx = ldx;
+  a.add = add; a.ldadd = ldadd; a.y = y; a.ldy = ldy;
+  a.n_rows = (int)n_rows; a.n_cols = (int)n_cols; a.width = (int)width;
+  a.mean = reduce == INCAGG_REDUCE_MEAN; a.scale = scale; a.add_scale = add_scale;
+  rc = error_flag_address(&a.err);
+  if (rc) return rc;
+  const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(add, ldadd) && rows_vec4(y, ldy);
+  return dispatch_spmm<false>(a, vec4, max_row_nnz, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col,
+                                          const float *val, const float *x, int64_t ldx,
+                                          const float *m_in, int64_t ldin, const float *m_ag,
+                                          int64_t ldag, int64_t n_rows, int64_t width, int reduce,
+                                          float scale, const float *add, int64_t ldadd,
+                                          float add_scale, int64_t max_row_nnz, float *h,
+                                          int64_t ldh, void *stream) {
+  int rc = check_common(rowptr, col, x, ldx, n_rows, n_rows, width, reduce, add, ldadd, h, ldh);
+  if (rc) return rc;
+  if (n_rows == 0 || width == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(m_in && m_ag, "null m_in or m_ag");
+  INCAGG_REQUIRE(ldin >= width && ldag >= width, "ldin/ldag smaller than width");
+  INCAGG_REQUIRE((const void *)m_in != (const void *)h, "h must not alias m_in");
+  SpmmArgs a{};
+  a.rowptr = rowptr; a.col = col; a.val = val; a.x = x; a.ldx = ldx;
+  a.m_in = m_in; a.ldin = ldin; a.m_ag = m_ag; a.ldag = ldag;
+  a.add = add; a.ldadd = ldadd; a.y = h; a.ldy = ldh;
+  a.n_rows = (int)n_rows; a.n_cols = (int)n_rows; a.width = (int)width;
+  a.mean = reduce == INCAGG_REDUCE_MEAN; a.scale = scale; a.add_scale = add_scale;
+  rc = error_flag_address(&a.err);
+  if (rc) return rc;
+  const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(m_in, ldin) &&
+                    rows_vec4(m_ag, ldag) && rows_vec4(add, ldadd) && rows_vec4(h, ldh);
+  return dispatch_spmm<true>(a, vec4, max_row_nnz, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, int64_t ldb,
+                                   int64_t n_rows, int64_t width, float *d, int64_t ldd,
+                                   void *stream) {
+  INCAGG_REQUIRE(n_rows >= 0 && width >= 0 && width < INT_MAX, "bad size");
+  if (n_rows == 0 || width == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(a && b && d, "null pointer");
+  INCAGG_REQUIRE(lda >= width && ldb >= width && ldd >= width, "leading dimension < width");
+  const bool vec4 = width % 4 == 0 && rows_vec4(a, lda) && rows_vec4(b, ldb) && rows_vec4(d, ldd);
+  const long long items = n_rows * (width / (vec4 ? 4 : 1));
+  const int blocks = (int)std::min<long long>((items + 255) / 256, 2048);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec4)
+    hipLaunchKernelGGL((rows_sub_kernel<4>), dim3(blocks), dim3(256), 0, s, a, lda, b, ldb, n_rows,
+                       (int)width, d, ldd);
+  else
+    hipLaunchKernelGGL((rows_sub_kernel<1>), dim3(blocks), dim3(256), 0, s, a, lda, b, ldb, n_rows,
+                       (int)width, d, ldd);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}

@@ -1,0 +1,31 @@
+"""MI355X-native drop-in for the ``torch_geometric_autoscale`` package of AMShek/IncAgg-GNN.
+
+Importing the package loads ``libincagg_gnn.so`` (hand-written HIP kernels behind a C ABI)
+and registers the reference's five native operators in
+``torch.ops.torch_geometric_autoscale`` (torch_geometric_autoscale/__init__.py:8-10 loads
+``_relabel`` / ``_async`` for the same purpose).
+"""
+from . import _lib
+from . import ops
+
+_lib.lib()  # fail loudly at import time when the native library has not been built
+ops.register_torch_ops()
+
+from .sparse import SparseTensor  # noqa: E402
+from .data import Data, get_data, gcn_norm, synthetic_graph  # noqa: E402
+from .history import History  # noqa: E402
+from .pool import AsyncIOPool  # noqa: E402
+from .metis import metis, permute  # noqa: E402
+from .utils import compute_micro_f1, gen_masks, dropout, index2mask  # noqa: E402
+from .loader import SubgraphLoader, EvalSubgraphLoader, SubData  # noqa: E402
+from .aggregate import spmm, incagg_aggregate  # noqa: E402
+from . import models  # noqa: E402
+
+__version__ = '0.1.0'
+
+__all__ = [
+    'SparseTensor', 'Data', 'get_data', 'gcn_norm', 'synthetic_graph', 'History', 'AsyncIOPool',
+    'metis', 'permute', 'compute_micro_f1', 'gen_masks', 'dropout', 'index2mask',
+    'SubgraphLoader', 'EvalSubgraphLoader', 'SubData', 'spmm', 'incagg_aggregate', 'models',
+    '__version__',
+]

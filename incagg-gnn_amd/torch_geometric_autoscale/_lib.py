@@ -1,0 +1,96 @@
+"""ctypes binding of ``libincagg_gnn.so`` (the C ABI declared in ``include/incagg_gnn.h``).
+
+The library is the only implementation of the hot path: there is no Python or
+PyTorch fallback.  If the shared object is missing every entry point raises.
+"""
+import ctypes
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "INCAGG_GNN_LIB", os.path.join(os.path.dirname(_PKG_DIR), "lib", "libincagg_gnn.so"))
+
+_c = ctypes
+_i64, _i32, _f32, _vp, _int = _c.c_int64, _c.c_int32, _c.c_float, _c.c_void_p, _c.c_int
+
+# name -> (restype, argtypes); mirrors include/incagg_gnn.h one to one.
+SIGNATURES = {
+    "incagg_last_error": (_c.c_char_p, []),
+    "incagg_abi_version": (_int, []),
+    "incagg_device_count": (_int, []),
+    "incagg_check_device_errors": (_int, []),
+    "incagg_spmm_csr_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _f32, _vp,
+                                   _i64, _f32, _i64, _vp, _i64, _vp]),
+    "incagg_spmm_csr_incagg_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
+                                          _i64, _int, _f32, _vp, _i64, _f32, _i64, _vp, _i64, _vp]),
+    "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "incagg_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "incagg_scatter_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "incagg_copy_row_chunks_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp,
+                                          _i64, _int, _vp]),
+    "incagg_stage_read_async": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
+                                       _i64, _vp]),
+    "incagg_stage_synchronize": (_int, []),
+    "incagg_stage_write_async": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "incagg_stage_pending": (_i64, []),
+    "incagg_relabel_bound": (_i64, [_vp, _i64, _vp, _i64]),
+    "incagg_relabel_one_hop": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp,
+                                      _vp, _vp]),
+    "incagg_relabel_one_hop_within_batch": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _int, _vp,
+                                                   _vp, _vp, _vp, _vp]),
+    "incagg_csr_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+}
+
+REDUCE = {"sum": 0, "add": 0, "mean": 1}
+
+_handle = None
+
+
+class IncAggLibraryError(RuntimeError):
+    pass
+
+
+class IncAggIndexError(RuntimeError, IndexError):
+    """Out-of-range row / chunk: the reference's "Invalid index" assertion
+    (csrc/cuda/async_cuda.cu:77-78,148-149), which surfaces as a RuntimeError."""
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _handle
+    if _handle is None:
+        if not os.path.isfile(LIB_PATH):
+            raise IncAggLibraryError(
+                f"{LIB_PATH} not found: build it with `make -C incagg-gnn_amd/csrc` "
+                "(there is no fallback implementation)")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError here means header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if h.incagg_abi_version() != 1:
+            raise IncAggLibraryError("libincagg_gnn.so ABI version mismatch")
+        _handle = h
+    return _handle
+
+
+def last_error() -> str:
+    return lib().incagg_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Turns a negative status into the exception type the reference raises
+    (its AT_ASSERTM failures surface as RuntimeError)."""
+    if rc < 0:
+        msg = last_error()
+        if rc == -4:
+            raise IncAggIndexError(msg)
+        raise RuntimeError(msg)
+
+
+def device_count() -> int:
+    return int(lib().incagg_device_count())
+
+
+def check_device_errors() -> None:
+    check(lib().incagg_check_device_errors())

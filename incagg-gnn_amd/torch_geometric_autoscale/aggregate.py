@@ -1,0 +1,132 @@
+"""Differentiable neighbour aggregation on top of the HIP kernels.
+
+``spmm``            y = scale * reduce(A, x) + add_scale * add
+``incagg_aggregate``  h = scale * (reduce(A_ib, x - M_in) + M_ag) + add_scale * add
+                    (the incremental aggregate of models/gcn2.py:255 and its siblings)
+
+The backward pass of both is dX = scale * A^T dY: the same row-parallel kernel run on
+the transposed CSR cached on the adjacency, so no atomics are involved
+(autograd through every aggregation call site, main.py:81).
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .sparse import SparseTensor
+
+
+def _as_rows(x: Tensor) -> Tensor:
+    if x.dim() != 2:
+        raise ValueError(f"expected a [rows, width] matrix, got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise TypeError(f"aggregation computes in float32, got {x.dtype}")
+    if x.size(1) > 1 and x.stride(1) != 1:
+        x = x.contiguous()
+    return x
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, add, adj, reduce, scale, add_scale):
+        rowptr, col, val = adj.device_csr()
+        y = ops.spmm_csr(rowptr, col, val, x, adj.size(1), reduce, scale, add, add_scale,
+                         adj.max_row_nnz())
+        ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
+        ctx.x_rows = x.size(0)
+        ctx.has_add = add is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = dadd = None
+        dy = _as_rows(dy)
+        if ctx.needs_input_grad[0]:
+            dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, ctx.x_rows)
+        if ctx.has_add and ctx.needs_input_grad[1]:
+            dadd = dy * ctx.add_scale
+        return dx, dadd, None, None, None, None
+
+
+class _IncAgg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, add, m_in, m_ag, adj, reduce, scale, add_scale):
+        rowptr, col, val = adj.device_csr()
+        h = ops.spmm_csr_incagg(rowptr, col, val, x, m_in, m_ag, reduce, scale, add, add_scale,
+                                adj.max_row_nnz())
+        ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
+        ctx.x_rows = x.size(0)
+        ctx.has_add = add is not None
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = dadd = None
+        dy = _as_rows(dy)
+        if ctx.needs_input_grad[0]:
+            dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, ctx.x_rows)
+        if ctx.has_add and ctx.needs_input_grad[1]:
+            dadd = dy * ctx.add_scale
+        return dx, dadd, None, None, None, None, None, None
+
+
+def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: float,
+                          x_rows: int) -> Tensor:
+    t_rowptr, t_col, t_val, t_max = adj.device_csr_t(reduce)
+    n_cols = adj.size(1)
+    dx = ops.spmm_csr(t_rowptr, t_col, t_val, dy, adj.size(0), "sum", scale, None, 0.0, t_max)
+    if x_rows > n_cols:  # x had rows the adjacency never references
+        pad = torch.zeros((x_rows - n_cols, dy.size(1)), dtype=dy.dtype, device=dy.device)
+        dx = torch.cat([dx, pad], dim=0)
+    return dx
+
+
+def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
+         add: Optional[Tensor] = None, add_scale: float = 0.0) -> Tensor:
+    """``adj @ x`` / ``spmm(adj, x, reduce)`` with an optional fused ``+ add_scale * add``."""
+    if reduce not in ("sum", "add", "mean"):
+        raise ValueError(f"unsupported reduce '{reduce}'")
+    x = _as_rows(x)
+    if add is not None:
+        add = _as_rows(add)
+    return _SpMM.apply(x, add, adj, "mean" if reduce == "mean" else "sum", float(scale),
+                       float(add_scale))
+
+
+def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,
+                     reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
+                     add_scale: float = 0.0, fused: bool = True) -> Tensor:
+    """``adj @ (x - m_in) + m_ag`` in one launch; ``m_in`` / ``m_ag`` are constants
+    (the reference detaches both, models/gcn2.py:246-247)."""
+    if adj.size(0) != adj.size(1):
+        raise ValueError("the incremental aggregate needs the square in-batch adjacency")
+    x = _as_rows(x)
+    b = adj.size(0)
+    if x.size(0) < b:
+        raise ValueError("x has fewer rows than the batch")
+    m_in, m_ag = m_in.detach(), m_ag.detach()
+    if add is not None:
+        add = _as_rows(add)
+    red = "mean" if reduce == "mean" else "sum"
+    if fused:
+        return _IncAgg.apply(x, add, m_in, m_ag, adj, red, float(scale), float(add_scale))
+    # two-pass form: one streaming subtract, then the plain aggregation with M_ag
+    # folded in afterwards; gathers touch one operand instead of two.
+    d = _RowsSub.apply(x[:b], m_in)
+    h = _SpMM.apply(d, None, adj, red, 1.0, 0.0) + m_ag[:b, :x.size(1)]
+    if scale != 1.0:
+        h = h * scale
+    if add is not None:
+        h = h + add_scale * add[:b]
+    return h
+
+
+class _RowsSub(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.rows_sub(_as_rows(a), b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None

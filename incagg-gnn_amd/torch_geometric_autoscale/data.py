@@ -1,0 +1,161 @@
+"""A small ``Data`` container (the slice of ``torch_geometric.data.Data`` the loaders use,
+loader.py:187-190) and seeded synthetic graphs shaped like the benchmark datasets.
+
+Datasets are never downloaded: ``get_data`` builds a synthetic graph with the public
+size statistics of the named dataset (optionally scaled down), planted in ``num_parts``
+communities so that a partition-contiguous ``(perm, ptr)`` exists by construction.
+"""
+from typing import Dict, Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .sparse import SparseTensor
+
+
+class Data:
+    """Attribute bag; tensors whose first dimension equals ``num_nodes`` are node-level."""
+
+    def __init__(self, **kwargs):
+        self.__dict__['_store'] = {}
+        for k, v in kwargs.items():
+            self._store[k] = v
+
+    def __getattr__(self, key):
+        store = self.__dict__['_store']
+        if key in store:
+            return store[key]
+        raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        self._store[key] = value
+
+    def __getitem__(self, key):
+        return self._store[key]
+
+    def __setitem__(self, key, value):
+        self._store[key] = value
+
+    def __contains__(self, key):
+        return key in self._store
+
+    def __iter__(self) -> Iterator[Tuple[str, object]]:
+        return iter(list(self._store.items()))
+
+    def keys(self):
+        return list(self._store.keys())
+
+    @property
+    def num_nodes(self) -> int:
+        if 'num_nodes' in self._store:
+            return self._store['num_nodes']
+        if 'x' in self._store and self._store['x'] is not None:
+            return self._store['x'].size(0)
+        if 'adj_t' in self._store:
+            return self._store['adj_t'].size(1)
+        raise AttributeError('num_nodes')
+
+    def to(self, device, *args, **kwargs) -> "Data":
+        out = Data()
+        for k, v in self._store.items():
+            out._store[k] = v.to(device, *args, **kwargs) if hasattr(v, 'to') else v
+        return out
+
+    def __repr__(self):
+        parts = []
+        for k, v in self._store.items():
+            parts.append(f"{k}={list(v.shape)}" if isinstance(v, Tensor) else f"{k}={v}")
+        return f"Data({', '.join(parts)})"
+
+
+# Public size statistics of the benchmark graphs (nodes, directed edges after
+# symmetrisation, input width, classes).
+DATASET_STATS: Dict[str, Tuple[int, int, int, int]] = {
+    'flickr': (89_250, 899_756, 500, 7),
+    'arxiv': (169_343, 2_315_598, 128, 40),
+    'products': (2_449_029, 123_718_280, 100, 47),
+    'reddit': (232_965, 23_213_838, 602, 41),
+}
+
+
+def synthetic_graph(num_nodes: int, num_edges: int, num_parts: int, cross_fraction: float = 0.15,
+                    exponent: float = 2.1, seed: int = 0,
+                    max_degree_fraction: float = 0.02) -> Tuple[SparseTensor, Tensor]:
+    """Symmetric power-law graph planted in ``num_parts`` contiguous communities.
+
+    Returns ``(adj_t, ptr)``: a value-less CSR without self loops or duplicates, and
+    ``ptr[num_parts + 1]`` community boundaries (part ``p`` owns ids ``[ptr[p], ptr[p+1])``,
+    the contract of metis.py:32-33 after ``permute``).  ``cross_fraction`` of the
+    edge endpoints leave their community.  Chung-Lu style: endpoints are drawn with
+    probability proportional to a power-law weight.
+    """
+    rng = np.random.default_rng(seed)
+    bounds = np.linspace(0, num_nodes, num_parts + 1).astype(np.int64)
+    part_of = np.repeat(np.arange(num_parts), np.diff(bounds))
+    # power-law expected degrees, capped so that one hub cannot dominate tiny graphs
+    w = (rng.pareto(exponent - 1.0, size=num_nodes) + 1.0)
+    w = np.minimum(w, max(4.0, max_degree_fraction * num_nodes))
+    half = num_edges // 2
+    # source endpoints ~ w (global)
+    cdf = np.cumsum(w)
+    src = np.searchsorted(cdf, rng.random(half) * cdf[-1]).astype(np.int64)
+    src = np.minimum(src, num_nodes - 1)
+    # destination: inside the source's community (by local weight) or anywhere
+    cross = rng.random(half) < cross_fraction
+    dst = np.empty(half, dtype=np.int64)
+    dst_cross = np.searchsorted(cdf, rng.random(int(cross.sum())) * cdf[-1])
+    dst[cross] = np.minimum(dst_cross, num_nodes - 1)
+    p = part_of[src[~cross]]
+    lo, hi = bounds[p], bounds[p + 1]
+    base = np.where(lo > 0, cdf[np.maximum(lo - 1, 0)], 0.0)
+    top = cdf[hi - 1]
+    target = base + rng.random(p.size) * (top - base)
+    dst[~cross] = np.clip(np.searchsorted(cdf, target), lo, hi - 1)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    r = np.concatenate([src, dst])
+    c = np.concatenate([dst, src])
+    key = np.unique(r * num_nodes + c)
+    r, c = key // num_nodes, key % num_nodes
+    rowptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=num_nodes), out=rowptr[1:])
+    adj_t = SparseTensor(rowptr=torch.from_numpy(rowptr), col=torch.from_numpy(c.astype(np.int64)),
+                         sparse_sizes=(num_nodes, num_nodes), is_sorted=True)
+    return adj_t, torch.from_numpy(bounds)
+
+
+def gcn_norm(adj_t: SparseTensor, add_self_loops: bool = False) -> SparseTensor:
+    """``D^-1/2 A D^-1/2`` with ``deg`` = row sums and ``inf -> 0`` (main.py:150-151)."""
+    if add_self_loops:
+        adj_t = adj_t.set_diag()
+    if not adj_t.has_value():
+        adj_t = adj_t.fill_value(1.0)
+    row, col, value = adj_t.coo()
+    deg = torch.zeros(adj_t.size(0), dtype=value.dtype).index_add_(0, row, value)
+    dis = deg.pow(-0.5)
+    dis[dis == float('inf')] = 0
+    return adj_t.set_value(dis[row] * value * dis[col])
+
+
+def get_data(root: Optional[str], name: str, num_parts: int = 16, scale: float = 1.0,
+             cross_fraction: float = 0.15, seed: int = 0, features: bool = True):
+    """``(data, in_channels, out_channels)`` like data.py:118-145, on a synthetic graph with
+    the named dataset's statistics (``scale`` shrinks nodes and edges together).
+    ``data.ptr`` holds the planted partition boundaries."""
+    key = name.lower().replace('ogbn-', '')
+    if key not in DATASET_STATS:
+        raise NotImplementedError(f"unknown dataset '{name}'")
+    n, e, f_in, n_cls = DATASET_STATS[key]
+    n, e = max(int(n * scale), num_parts * 4), max(int(e * scale), num_parts * 8)
+    adj_t, ptr = synthetic_graph(n, e, num_parts, cross_fraction, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    data = Data(adj_t=adj_t, num_nodes=n, ptr=ptr)
+    if features:
+        data.x = torch.randn(n, f_in, generator=g)
+    data.y = torch.randint(0, n_cls, (n,), generator=g)
+    split = torch.rand(n, generator=g)
+    data.train_mask = split < 0.6
+    data.val_mask = (split >= 0.6) & (split < 0.8)
+    data.test_mask = split >= 0.8
+    return data, f_in, n_cls

@@ -1,0 +1,154 @@
+"""Partition mini-batch construction (interface of loader.py:95-284): every batch is a
+union of whole partitions plus, for the push/pull and sweep paths, its one-hop halo.
+
+A batch is the tuple ``SubData(data, batch_size, n_id, offset, count)``:
+``data.adj_t`` is the local ``[B, M]`` (or ``[B, B]``) CSR produced by the native
+relabelling, ``data.x = x[n_id]``, ``offset`` / ``count`` the contiguous global row
+ranges of the batch's partitions.  The transposed CSR for the backward pass and the
+in-batch / halo split are derived once per batch object, never per training step.
+"""
+import random
+import time
+from typing import List, NamedTuple, Tuple
+
+import torch
+from torch import Tensor
+from torch.utils.data import DataLoader
+
+from . import ops
+from .data import Data
+from .sparse import SparseTensor
+
+
+class SubData(NamedTuple):
+    data: Data
+    batch_size: int
+    n_id: Tensor  # The indices of mini-batched nodes
+    offset: Tensor  # The offset of contiguous mini-batched nodes
+    count: Tensor  # The number of contiguous mini-batched nodes
+
+    def to(self, *args, **kwargs):
+        return SubData(self.data.to(*args, **kwargs), self.batch_size, self.n_id, self.offset,
+                       self.count)
+
+
+def sample_neighbors(src: SparseTensor, num_neighbors: int,
+                     unsampled_n_id: Tensor = None) -> Tuple[SparseTensor, Tensor]:
+    """Keeps at most ``num_neighbors`` random edges per row, columns in their original
+    order (loader.py:32-93); ``num_neighbors < 0`` keeps everything."""
+    if num_neighbors < 0:
+        return src, unsampled_n_id
+    rowptr, col, value = src.csr()
+    deg = rowptr[1:] - rowptr[:-1]
+    # random key per edge; keep the `num_neighbors` smallest of every row, order preserved
+    key = torch.rand(col.numel())
+    row = src.storage.row()
+    order = torch.argsort(row.to(torch.float64) + key.to(torch.float64) * 0.999999, stable=True)
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel())
+    keep = (rank - rowptr[row]) < num_neighbors
+    new_deg = torch.minimum(deg, torch.full_like(deg, num_neighbors))
+    new_rowptr = torch.zeros_like(rowptr)
+    new_rowptr[1:] = torch.cumsum(new_deg, 0)
+    out = SparseTensor(rowptr=new_rowptr, col=col[keep],
+                       value=None if value is None else value[keep],
+                       sparse_sizes=src.sparse_sizes(), is_sorted=True)
+    return out, unsampled_n_id
+
+
+class SubgraphLoader(DataLoader):
+    r"""A simple subgraph loader that, given a pre-partioned :obj:`data` object,
+    generates subgraphs from mini-batches in :obj:`ptr` (including their 1-hop
+    neighbors)."""
+
+    def __init__(self, data: Data, ptr: Tensor, batch_size: int = 1, bipartite: bool = True,
+                 log: bool = True, num_neighbors=-1, type='eval', IB=False, **kwargs):
+        self.data = data
+        self.ptr = ptr
+        self.bipartite = bipartite
+        self.log = log
+        self.num_neighbors = num_neighbors
+        if 'shuffle' in kwargs:
+            self.shuffle = kwargs['shuffle']
+        self.shuffled_batch_id = []
+
+        n_id = torch.arange(data.num_nodes)
+        batches = n_id.split((ptr[1:] - ptr[:-1]).tolist())
+        batches = [(i, batches[i]) for i in range(len(batches))]
+
+        if type == 'train':
+            collate = self.compute_subgraph_IB if IB else self.compute_subgraph_NS
+            super().__init__(batches, batch_size=batch_size, collate_fn=collate, **kwargs)
+        elif batch_size > 1:
+            super().__init__(batches, batch_size=batch_size, collate_fn=self.compute_subgraph,
+                             **kwargs)
+        else:  # If `batch_size=1`, we pre-process the subgraph generation:
+            if log:
+                t = time.perf_counter()
+                print('Pre-processing subgraphs...', end=' ', flush=True)
+            data_list = list(DataLoader(batches, batch_size=batch_size,
+                                        collate_fn=self.compute_subgraph, **kwargs))
+            if log:
+                print(f'Done! [{time.perf_counter() - t:.2f}s]')
+            super().__init__(data_list, batch_size=batch_size, collate_fn=lambda x: x[0], **kwargs)
+
+    def _batch_header(self, batches: List[Tuple[int, Tensor]]):
+        batch_ids, n_ids = zip(*batches)
+        n_id = torch.cat(n_ids, dim=0)
+        batch_id = torch.tensor(batch_ids)
+        offset = self.ptr[batch_id]
+        count = self.ptr[batch_id + 1] - offset
+        return n_id, n_id.numel(), offset, count
+
+    def _finish(self, rowptr, col, value, n_id, batch_size, offset, count) -> SubData:
+        adj_t = SparseTensor(rowptr=rowptr, col=col, value=value,
+                             sparse_sizes=(rowptr.numel() - 1, n_id.numel()), is_sorted=True)
+        data = self.data.__class__(adj_t=adj_t)
+        for k, v in self.data:
+            if isinstance(v, Tensor) and v.dim() > 0 and v.size(0) == self.data.num_nodes:
+                data[k] = v.index_select(0, n_id)
+        return SubData(data, batch_size, n_id, offset, count)
+
+    def compute_subgraph(self, batches: List[Tuple[int, Tensor]]) -> SubData:
+        """Batch rows plus their full one-hop halo (loader.py:172-192)."""
+        n_id, batch_size, offset, count = self._batch_header(batches)
+        rowptr, col, value = self.data.adj_t.csr()
+        rowptr, col, value, n_id = ops.relabel_one_hop(rowptr, col, value, n_id, self.bipartite)
+        return self._finish(rowptr, col, value, n_id, batch_size, offset, count)
+
+    def compute_subgraph_IB(self, batches: List[Tuple[int, Tensor]]) -> SubData:
+        """In-batch edges only -- the batches of the incremental-aggregation training
+        path (loader.py:194-214)."""
+        n_id, batch_size, offset, count = self._batch_header(batches)
+        rowptr, col, value = self.data.adj_t.csr()
+        rowptr, col, value, n_id = ops.relabel_one_hop_within_batch(rowptr, col, value, n_id,
+                                                                    self.bipartite)
+        return self._finish(rowptr, col, value, n_id, batch_size, offset, count)
+
+    def compute_subgraph_NS(self, batches: List[Tuple[int, Tensor]]) -> SubData:
+        """One-hop batch with optional per-row neighbour sampling (loader.py:217-246)."""
+        n_id, batch_size, offset, count = self._batch_header(batches)
+        rowptr, col, value = self.data.adj_t.csr()
+        rowptr, col, value, n_id = ops.relabel_one_hop(rowptr, col, value, n_id, self.bipartite)
+        if self.num_neighbors is not None and self.num_neighbors >= 0:
+            adj_t = SparseTensor(rowptr=rowptr, col=col, value=value,
+                                 sparse_sizes=(rowptr.numel() - 1, n_id.numel()), is_sorted=True)
+            adj_t, n_id = sample_neighbors(adj_t, self.num_neighbors, n_id)
+            rowptr, col, value = adj_t.csr()
+        return self._finish(rowptr, col, value, n_id, batch_size, offset, count)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}()'
+
+
+class EvalSubgraphLoader(SubgraphLoader):
+    r"""Fixed-order loader over consecutive groups of ``batch_size`` partitions, with the
+    subgraphs built once up front (loader.py:266-284)."""
+
+    def __init__(self, data: Data, ptr: Tensor, batch_size: int = 1, bipartite: bool = True,
+                 log: bool = True, **kwargs):
+        ptr = ptr[::batch_size]
+        if int(ptr[-1]) != data.num_nodes:
+            ptr = torch.cat([ptr, torch.tensor([data.num_nodes])], dim=0)
+        super().__init__(data=data, ptr=ptr, batch_size=1, bipartite=bipartite, log=log,
+                         shuffle=False, num_workers=0, **kwargs)

@@ -1,0 +1,461 @@
+"""``ScalableGNN``: history-based mini-batch execution of a GNN (interface of the
+reference's models/base.py:26-709) over the HIP aggregation and History-row kernels.
+
+One indexing convention is used throughout (the reference mixes two, see
+models/base.py:544-579 against models/gcn2.py:129-138):
+
+* ``histories[i]``    holds the INPUT rows of layer ``i`` (``i = 0``: the embedded
+  features, zero-padded to the table width) -- "M_in";
+* ``histories_ag[i]`` holds the full one-hop aggregate of ``histories[i]`` -- "M_ag";
+
+exactly what the refresh sweep writes (models/gcn.py:367-369,387,390).  The classic
+push/pull forward therefore pushes the output of layer ``i`` to ``histories[i + 1]``
+and pulls the out-of-batch rows of ``histories[i + 1]``; it issues as many pulls as it
+consumes.
+
+Subclasses provide three small hooks -- :meth:`_embed`, :meth:`_update`,
+:attr:`agg_reduce` -- from which this class builds ``forward`` (push/pull),
+``VR_forward`` (incremental aggregation), ``forward_layer`` and both refresh sweeps.
+There are no device-wide synchronisations anywhere in these paths.
+"""
+import warnings
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import ops
+from ..aggregate import incagg_aggregate, spmm
+from ..history import History
+from ..nn import unweighted
+from ..pool import AsyncIOPool
+from ..sparse import SparseTensor
+
+
+class ScalableGNN(torch.nn.Module):
+    r"""An abstract class for implementing scalable GNNs via historical embeddings.
+
+    Args:
+        num_nodes (int): The number of nodes in the graph.
+        hidden_channels (int): Width of every History table.
+        num_layers (int): The number of layers of the model.
+        pool_size (int, optional): Number of staging slots for host-resident tables.
+        buffer_size (int, optional): Rows per staging slot.
+        device: Where the History tables live (``None`` / ``'cpu'`` = pinned host
+            memory, ``'cuda:i'`` = HBM).
+    """
+
+    def __init__(self, num_nodes: int, hidden_channels: int, num_layers: int,
+                 pool_size: Optional[int] = None, buffer_size: Optional[int] = None,
+                 device=None, in_channels=None):
+        super().__init__()
+        self.num_nodes = num_nodes
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self.pool_size = num_layers - 1 if pool_size is None else pool_size
+        self.buffer_size = buffer_size
+
+        self.histories = torch.nn.ModuleList(
+            [History(num_nodes, hidden_channels, device) for _ in range(num_layers)])
+        self.pool: Optional[AsyncIOPool] = None
+        self.histories_ag = torch.nn.ModuleList(
+            [History(num_nodes, hidden_channels, device) for _ in range(num_layers)])
+        self.pool_ag: Optional[AsyncIOPool] = None
+
+        self._async = False
+        self.__out: Optional[Tensor] = None
+        # use one launch for A (x - M_in) + M_ag (True) or subtract first (False)
+        self.fused_incagg = True
+
+    # ------------------------------------------------------------------ placement
+    @property
+    def emb_device(self):
+        return self.histories[0].emb.device
+
+    @property
+    def device(self):
+        return self.histories[0]._device
+
+    def _apply(self, fn: Callable, *args, **kwargs) -> None:
+        super()._apply(fn, *args, **kwargs)
+        # Staging pools exist only when the tables are on the host and the model on a GPU.
+        if (str(self.emb_device) == 'cpu' and str(self.device)[:4] == 'cuda'
+                and self.pool_size is not None and self.buffer_size is not None):
+            self.pool = AsyncIOPool(self.pool_size, self.buffer_size,
+                                    self.histories[0].embedding_dim)
+            self.pool.to(self.device)
+            self.pool_ag = AsyncIOPool(self.pool_size, self.buffer_size,
+                                       self.histories_ag[0].embedding_dim)
+            self.pool_ag.to(self.device)
+        return self
+
+    def reset_parameters(self):
+        for history in self.histories:
+            history.reset_parameters()
+        for history in self.histories_ag:
+            history.reset_parameters()
+
+    # ------------------------------------------------------------------ hooks
+    agg_reduce = "sum"
+
+    def _embed(self, x: Tensor, state: Dict[str, Any], batch_size: int) -> Tensor:
+        """Layer-0 input rows from raw features (may fill ``state``)."""
+        raise NotImplementedError
+
+    def _update(self, layer: int, agg: Tensor, x: Tensor, state: Dict[str, Any],
+                pre: bool = False) -> Tensor:
+        """Everything of layer ``layer`` after the aggregation of its input ``x``
+        (``pre``: the aggregate is of :meth:`_pre_aggregate`'s output instead)."""
+        raise NotImplementedError
+
+    def _pre_aggregate(self, layer: int, x: Tensor) -> Optional[Tensor]:
+        """Optionally a narrower, linearly transformed ``x`` to aggregate instead (only the
+        push/pull forward uses it; the history tables always hold un-transformed rows)."""
+        return None
+
+    def _mix(self, layer: int, state: Dict[str, Any], batch_size: int):
+        """Optional ``(scale, add, add_scale)`` to fold into the aggregation epilogue, i.e.
+        the layer consumes ``scale * agg + add_scale * add`` (models/appnp.py:85);
+        :meth:`_update_mixed` then receives that instead of the raw aggregate."""
+        return None
+
+    def _update_mixed(self, layer: int, mixed: Tensor, x: Tensor, state: Dict[str, Any]) -> Tensor:
+        raise NotImplementedError
+
+    _layer_dropout = True  # dropout on the input of every layer after the first
+
+    def _adj(self, adj_t: SparseTensor) -> SparseTensor:
+        return unweighted(adj_t) if self.agg_reduce == "mean" else adj_t
+
+    def _aggregate(self, adj_t: SparseTensor, x: Tensor) -> Tensor:
+        return spmm(self._adj(adj_t), x, reduce=self.agg_reduce)
+
+    def _drop(self, x: Tensor) -> Tensor:
+        p = getattr(self, "dropout", 0.0)
+        return F.dropout(x, p=p, training=self.training) if p > 0 else x
+
+    def _layer_input(self, layer: int, x: Tensor) -> Tensor:
+        return self._drop(x) if layer > 0 and self._layer_dropout else x
+
+    # ------------------------------------------------------------------ calls
+    def __call__(self, x: Optional[Tensor] = None, adj_t: Optional[SparseTensor] = None,
+                 batch_size: Optional[int] = None, n_id: Optional[Tensor] = None,
+                 offset: Optional[Tensor] = None, count: Optional[Tensor] = None,
+                 loader=None, drift_norm: int = 2, aggregate_combined: bool = True,
+                 use_aggregation: bool = True, **kwargs):
+        r"""Push/pull forward (models/base.py:126-240): starts the pulls of the
+        out-of-batch rows of every layer, runs :meth:`forward`, waits for the pushes.
+        Returns a dict whose ``'out'`` entry is the model output."""
+        if loader is not None:
+            return self.mini_inference(loader, use_aggregation)
+
+        self._async = (self.pool is not None and batch_size is not None and n_id is not None
+                       and offset is not None and count is not None)
+        if (batch_size is not None and not self._async and str(self.emb_device) == 'cpu'
+                and str(self.device)[:4] == 'cuda'):
+            warnings.warn('Asynchronous I/O disabled, although history and '
+                          'model sit on different devices.')
+
+        if self._async and use_aggregation:
+            for hist in self.histories[1:]:
+                self.pool.async_pull(hist.emb, None, None, n_id[batch_size:])
+
+        out, t_move = self.forward(x, adj_t, drift_norm, aggregate_combined, use_aggregation,
+                                   batch_size, n_id, offset, count, **kwargs)
+
+        if self._async:
+            self.pool.synchronize_push()
+        self._async = False
+        return {'out': out, 'time_pool_pull': 0, 'time_pool_push': 0,
+                'time_forward_histories_movement': t_move, 'time_forward_total': 0}
+
+    def VR_call(self, x: Optional[Tensor] = None, adj_t: Optional[SparseTensor] = None,
+                batch_size: Optional[int] = None, n_id: Optional[Tensor] = None,
+                offset: Optional[Tensor] = None, count: Optional[Tensor] = None,
+                loader=None, debug_flag: bool = False, drift_norm: int = 2, epoch: int = 0,
+                batch_idx: int = 0, **kwargs):
+        r"""Incremental-aggregation forward (models/base.py:242-378): pulls the batch's
+        own rows of ``M_in`` / ``M_ag`` for every layer and runs :meth:`VR_forward`.
+        Nothing is pushed; the tables change only in :meth:`mini_inference_vr`."""
+        if loader is not None:
+            return self.mini_inference(loader)
+
+        self._async = (self.pool is not None and batch_size is not None and n_id is not None
+                       and offset is not None and count is not None)
+        if (batch_size is not None and not self._async and str(self.emb_device) == 'cpu'
+                and str(self.device)[:4] == 'cuda'):
+            warnings.warn('Asynchronous I/O disabled, although history and '
+                          'model sit on different devices.')
+
+        if self._async:
+            empty = torch.empty(0, dtype=torch.int64)
+            for i in range(len(self.histories)):
+                self.pool.async_pull(self.histories[i].emb, offset, count, empty)
+                self.pool_ag.async_pull(self.histories_ag[i].emb, offset, count, empty)
+
+        out, t_move, n_ib, n_ob = self.VR_forward(x, adj_t, drift_norm, epoch, batch_idx,
+                                                  batch_size, n_id, offset, count, **kwargs)
+        self._async = False
+        return {'out': out, 'time_pool_pull': 0, 'time_pool_push': 0,
+                'time_forward_histories_movement': t_move, 'time_forward_total': 0,
+                'num_in_batch_neighbors': n_ib, 'num_out_batch_neighbors': n_ob}
+
+    # ------------------------------------------------------------------ push / pull primitives
+    def push_and_pull(self, history, x: Tensor, batch_size: Optional[int] = None,
+                      n_id: Optional[Tensor] = None, offset: Optional[Tensor] = None,
+                      count: Optional[Tensor] = None) -> Tuple[Tensor, float]:
+        r"""Pushes the in-batch rows of :obj:`x` to :obj:`history` and replaces the
+        out-of-batch rows by their historical values (models/base.py:380-456)."""
+        if n_id is None and x.size(0) != self.num_nodes:
+            return x, 0.0  # Do nothing...
+
+        if n_id is None and x.size(0) == self.num_nodes:
+            history.push(x)
+            return x, 0.0
+
+        assert n_id is not None
+
+        if batch_size is None:
+            history.push(x, n_id)
+            return x, 0.0
+
+        if not self._async:
+            history.push(x[:batch_size].detach(), n_id[:batch_size], offset, count)
+            h = history.pull(n_id[batch_size:])
+            return torch.cat([x[:batch_size], h], dim=0), 0.0
+
+        out = self.pool.synchronize_pull()[:n_id.numel() - batch_size]
+        self.pool.async_push(x[:batch_size].detach(), offset, count, history.emb)
+        out = torch.cat([x[:batch_size], out], dim=0)
+        self.pool.free_pull()
+        return out, 0.0
+
+    def push_only(self, history, x: Tensor, batch_size: Optional[int] = None,
+                  n_id: Optional[Tensor] = None, offset: Optional[Tensor] = None,
+                  count: Optional[Tensor] = None) -> Tuple[Tensor, float]:
+        """Pushes without pulling (models/base.py:458-499)."""
+        if n_id is None and x.size(0) != self.num_nodes:
+            return x, 0.0
+        if n_id is None and x.size(0) == self.num_nodes:
+            history.push(x)
+            return x, 0.0
+        assert n_id is not None
+        if batch_size is None:
+            history.push(x, n_id)
+            return x, 0.0
+        if not self._async:
+            history.push(x[:batch_size].detach(), n_id[:batch_size], offset, count)
+        else:
+            self.pool.async_push(x[:batch_size].detach(), offset, count, history.emb)
+        return x[:batch_size], 0.0
+
+    def _pull_batch_rows(self, layer: int, batch_size: int, n_id: Tensor, offset: Tensor,
+                         count: Tensor, width: int) -> Tuple[Tensor, Tensor]:
+        """The batch's own rows of M_in / M_ag of ``layer`` (what VR_forward consumes,
+        models/gcn2.py:246-247).  Views into slot memory when pools are in use."""
+        if self._async:
+            m_in = self.pool.synchronize_pull()[:batch_size, :width]
+            m_ag = self.pool_ag.synchronize_pull()[:batch_size, :width]
+            return m_in, m_ag
+        if offset is not None and count is not None:
+            m_in = self.histories[layer].pull_chunks(offset, count)
+            m_ag = self.histories_ag[layer].pull_chunks(offset, count)
+        else:
+            idx = n_id[:batch_size].to(self.emb_device)
+            m_in = self.histories[layer].pull(idx)
+            m_ag = self.histories_ag[layer].pull(idx)
+        return m_in[:batch_size, :width], m_ag[:batch_size, :width]
+
+    def _free_batch_rows(self) -> None:
+        if self._async:
+            self.pool.free_pull()
+            self.pool_ag.free_pull()
+
+    # ------------------------------------------------------------------ generic forward passes
+    def forward(self, x: Tensor, adj_t: SparseTensor, drift_norm: int = 2,
+                aggregate_combined: bool = True, use_aggregation: bool = True,
+                *args) -> Tuple[Tensor, float]:
+        """Push/pull training forward (e.g. models/gcn.py:97-205).  ``args`` =
+        (batch_size, n_id, offset, count)."""
+        batch_size, n_id, offset, count = (tuple(args) + (None,) * 4)[:4]
+        b = adj_t.size(0) if batch_size is None else batch_size
+        state: Dict[str, Any] = {}
+        x = self._embed(x, state, b)
+        if use_aggregation and not aggregate_combined:
+            adj_t = in_batch_columns(adj_t, b)
+        if not use_aggregation:
+            x = x[:b]
+        adj = self._adj(adj_t)
+        for i in range(self.num_layers):
+            x = self._layer_input(i, x)
+            if not use_aggregation:
+                h = self._update(i, x[:b], x, state)
+            else:
+                mix = self._mix(i, state, b)
+                xa = self._pre_aggregate(i, x)
+                if mix is not None:
+                    h = self._update_mixed(i, spmm(adj, x, self.agg_reduce, *mix), x, state)
+                elif xa is not None:
+                    h = self._update(i, spmm(adj, xa, reduce=self.agg_reduce), x, state, pre=True)
+                else:
+                    h = self._update(i, spmm(adj, x, reduce=self.agg_reduce), x, state)
+            if i < self.num_layers - 1:
+                nid = None if n_id is None else n_id.to(self.emb_device)
+                if use_aggregation:
+                    x, _ = self.push_and_pull(self.histories[i + 1], h, batch_size, nid, offset,
+                                              count)
+                else:
+                    x, _ = self.push_only(self.histories[i + 1], h, batch_size, nid, offset, count)
+            else:
+                x = h
+        return x, 0.0
+
+    def VR_forward(self, x: Tensor, adj_t: SparseTensor, drift_norm: int = 2, epoch: int = 0,
+                   batch_idx: int = 0, *args):
+        """Incremental-aggregation training forward (e.g. models/gcn2.py:187-323):
+        every layer computes ``A_ib (x - M_in) + M_ag`` over in-batch edges only."""
+        batch_size, n_id, offset, count = (tuple(args) + (None,) * 4)[:4]
+        b = batch_size
+        state: Dict[str, Any] = {}
+        x = self._embed(x, state, b)[:b]
+        adj = self._adj(adj_t)
+        for i in range(self.num_layers):
+            x = self._layer_input(i, x)
+            m_in, m_ag = self._pull_batch_rows(i, b, n_id, offset, count, x.size(1))
+            mix = self._mix(i, state, b)
+            if mix is None:
+                agg = incagg_aggregate(adj, x, m_in, m_ag, reduce=self.agg_reduce,
+                                       fused=self.fused_incagg)
+                x = self._update(i, agg, x, state)
+            else:
+                mixed = incagg_aggregate(adj, x, m_in, m_ag, self.agg_reduce, *mix,
+                                         fused=self.fused_incagg)
+                x = self._update_mixed(i, mixed, x, state)
+            self._free_batch_rows()
+        return x, 0.0, 0, 0
+
+    @torch.no_grad()
+    def forward_layer(self, layer: int, x: Tensor, adj_t: SparseTensor, state: Dict[str, Any],
+                      use_aggregation: bool = True) -> Tensor:
+        """One layer of the layer-wise evaluation (e.g. models/gcn.py:283-332)."""
+        b = adj_t.size(0)
+        if layer == 0:
+            x = self._embed(x, state, b)
+        if not use_aggregation:
+            x = x[:b]
+        x = self._layer_input(layer, x)
+        agg = self._aggregate(adj_t, x) if use_aggregation else x
+        return self._update(layer, agg, x, state)
+
+    # ------------------------------------------------------------------ refresh sweeps
+    @property
+    def _out(self):
+        if self.__out is None:
+            on_host = str(self.emb_device) == 'cpu'
+            self.__out = torch.empty(self.num_nodes, self.out_channels, device=self.emb_device,
+                                     pin_memory=on_host and torch.cuda.is_available())
+        return self.__out
+
+    def _push_rows(self, table: Tensor, rows: Tensor, offset: Tensor, count: Tensor, pool) -> None:
+        if pool is not None:
+            if rows.size(1) < table.size(1):  # pad to the table width (models/gcn.py:355-365)
+                rows = F.pad(rows, (0, table.size(1) - rows.size(1)))
+            pool.async_push(rows, offset, count, table)
+        elif rows.is_cuda:
+            ops.copy_row_chunks(table, rows, offset, count, packed_is_src=True, device=rows.device)
+        else:
+            src = 0
+            for o, c in zip(offset.tolist(), count.tolist()):
+                table[o:o + c, :rows.size(1)] = rows[src:src + c]
+                table[o:o + c, rows.size(1):] = 0
+                src += c
+
+    def _pull_layer_input(self, history: History, batch_size: int, n_id: Tensor, offset: Tensor,
+                          count: Tensor) -> Tensor:
+        """[in-batch rows by chunks ; out-of-batch rows by index] of one table, on the
+        compute device (what models/gcn.py:378-385 gets from the pool)."""
+        m = n_id.numel()
+        if self.device.type != 'cuda':
+            emb = history.emb
+            ib = torch.cat([emb[o:o + c] for o, c in zip(offset.tolist(), count.tolist())])
+            return torch.cat([ib, emb.index_select(0, n_id[batch_size:])])[:m]
+        out = torch.empty((m, history.embedding_dim), dtype=history.emb.dtype, device=self.device)
+        ops.copy_row_chunks(out, history.emb, offset, count, packed_is_src=False,
+                            device=self.device)
+        if m > batch_size:
+            ops.gather_rows(history.emb, n_id[batch_size:].to(self.device), out=out[batch_size:],
+                            device=self.device)
+        return out
+
+    @torch.no_grad()
+    def _sweep(self, loader, use_aggregation: bool, with_aggregates: bool) -> Tensor:
+        batches = [tuple(sub) + ({}, ) for sub in loader]
+        use_pool = self.pool is not None
+        pool = self.pool if use_pool else None
+        pool_ag = self.pool_ag if use_pool else None
+        last = self.num_layers - 1
+
+        def run_layer(i, x, adj_t, batch_size, offset, count, state):
+            agg = self._aggregate(adj_t, x) if use_aggregation else x[:batch_size]
+            if with_aggregates:
+                self._push_rows(self.histories_ag[i].emb, agg, offset, count, pool_ag)
+            out = self._update(i, agg, x, state)[:batch_size]
+            target = self._out if i == last else self.histories[i + 1].emb
+            self._push_rows(target, out, offset, count, pool)
+
+        for data, batch_size, n_id, offset, count, state in batches:
+            adj_t = data.adj_t.to(self.device)
+            x = self._embed(data.x.to(self.device), state, batch_size)
+            if with_aggregates:
+                self._push_rows(self.histories[0].emb, x[:batch_size], offset, count, pool)
+            run_layer(0, x, adj_t, batch_size, offset, count, state)
+        if use_pool:
+            pool.synchronize_push()
+            pool_ag.synchronize_push()
+
+        for i in range(1, self.num_layers):
+            if use_pool:  # prime the queue for the whole layer (models/gcn.py:378-379)
+                for _, batch_size, n_id, offset, count, _ in batches:
+                    pool.async_pull(self.histories[i].emb, offset, count, n_id[batch_size:])
+            for data, batch_size, n_id, offset, count, state in batches:
+                adj_t = data.adj_t.to(self.device)
+                if use_pool:
+                    x = pool.synchronize_pull()[:n_id.numel()]
+                else:
+                    x = self._pull_layer_input(self.histories[i], batch_size, n_id, offset, count)
+                run_layer(i, x, adj_t, batch_size, offset, count, state)
+                if use_pool:
+                    pool.free_pull()
+            if use_pool:
+                pool.synchronize_push()
+                pool_ag.synchronize_push()
+        return self._out
+
+    @torch.no_grad()
+    def mini_inference(self, loader, use_aggregation: bool = True) -> Tensor:
+        """Layer-wise evaluation that refreshes ``histories`` (models/base.py:509-603)."""
+        return self._sweep(loader, use_aggregation, with_aggregates=False)
+
+    @torch.no_grad()
+    def mini_inference_vr(self, loader, use_aggregation: bool = True) -> Tensor:
+        """Layer-wise evaluation that refreshes both ``histories`` (M_in) and
+        ``histories_ag`` (M_ag) (e.g. models/gcn2.py:433-507).  The aggregate of a
+        layer's input is computed once and used for M_ag and for the layer itself."""
+        return self._sweep(loader, use_aggregation, with_aggregates=True)
+
+
+def in_batch_columns(adj_t: SparseTensor, batch_size: int) -> SparseTensor:
+    """Edges whose column is an in-batch node, same sparse sizes (the ``in_batch_adj`` of
+    models/gcn.py:117-126), built once per adjacency instead of once per step."""
+    cache = getattr(adj_t, "_in_batch_view", None)
+    if cache is not None and cache[0] == batch_size:
+        return cache[1]
+    host = adj_t._host if adj_t._host is not None else adj_t
+    row, col, value = host.coo()
+    keep = col < batch_size
+    view = SparseTensor(row=row[keep], col=col[keep],
+                        value=None if value is None else value[keep],
+                        sparse_sizes=host.sparse_sizes(), is_sorted=True).to(adj_t.device())
+    adj_t._in_batch_view = (batch_size, view)
+    return view

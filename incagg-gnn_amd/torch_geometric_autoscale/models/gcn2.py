@@ -1,0 +1,87 @@
+"""GCNII on historical embeddings (constructor and module layout of models/gcn2.py:22-76)."""
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from torch.nn import BatchNorm1d, Linear, ModuleList
+
+from ..nn import GCN2Conv
+from .base import ScalableGNN
+
+
+class GCN2(ScalableGNN):
+    def __init__(self, num_nodes: int, in_channels, hidden_channels: int, out_channels: int,
+                 num_layers: int, alpha: float, theta: float, shared_weights: bool = True,
+                 dropout: float = 0.0, drop_input: bool = True, batch_norm: bool = False,
+                 residual: bool = False, pool_size: Optional[int] = None,
+                 buffer_size: Optional[int] = None, device=None):
+        super().__init__(num_nodes, hidden_channels, num_layers, pool_size, buffer_size, device,
+                         in_channels=in_channels)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.dropout = dropout
+        self.drop_input = drop_input
+        self.batch_norm = batch_norm
+        self.residual = residual
+
+        self.lins = ModuleList()
+        self.lins.append(Linear(in_channels, hidden_channels))
+        self.lins.append(Linear(hidden_channels, out_channels))
+
+        self.convs = ModuleList([
+            GCN2Conv(hidden_channels, alpha=alpha, theta=theta, layer=i + 1,
+                     shared_weights=shared_weights, normalize=False)
+            for i in range(num_layers)])
+        self.bns = ModuleList([BatchNorm1d(hidden_channels) for _ in range(num_layers)])
+
+    @property
+    def reg_modules(self):
+        return ModuleList(list(self.convs) + list(self.bns))
+
+    @property
+    def nonreg_modules(self):
+        return self.lins
+
+    def reset_parameters(self):
+        super().reset_parameters()
+        for lin in self.lins:
+            lin.reset_parameters()
+        for conv in self.convs:
+            conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+
+    # ---- hooks (the per-layer arithmetic of models/gcn2.py:326-346)
+    def _embed(self, x: Tensor, state: Dict[str, Any], batch_size: int) -> Tensor:
+        if self.drop_input:
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        x = x_0 = self.lins[0](x).relu_()
+        state['x_0'] = x_0[:batch_size]
+        return F.dropout(x, p=self.dropout, training=self.training)
+
+    def _post(self, layer: int, h: Tensor, x: Tensor) -> Tensor:
+        if self.batch_norm:
+            h = self.bns[layer](h)
+        if self.residual and h.size(-1) == x.size(-1):
+            h = h + x[:h.size(0)]
+        h = h.relu_()
+        if layer == self.num_layers - 1:
+            h = F.dropout(h, p=self.dropout, training=self.training)
+            h = self.lins[1](h)
+        return h
+
+    def _update(self, layer: int, agg: Tensor, x: Tensor, state: Dict[str, Any],
+                pre: bool = False) -> Tensor:
+        return self._post(layer, self.convs[layer].forward_after_propagate(agg, state['x_0']), x)
+
+    def _mix(self, layer: int, state: Dict[str, Any], batch_size: int):
+        conv = self.convs[layer]
+        if conv.weight2 is not None:
+            return None
+        return 1.0 - conv.alpha, state['x_0'], conv.alpha
+
+    def _update_mixed(self, layer: int, mixed: Tensor, x: Tensor, state: Dict[str, Any]) -> Tensor:
+        conv = self.convs[layer]
+        h = torch.addmm(mixed, mixed, conv.weight1, beta=1.0 - conv.beta, alpha=conv.beta)
+        return self._post(layer, h, x)

@@ -1,0 +1,399 @@
+"""Tensor-level entry points of the hot path.
+
+Every function here validates its tensors, then calls the C ABI
+(``include/incagg_gnn.h``) with raw pointers, sizes and the current HIP stream.
+PyTorch only supplies device memory and streams.  The five operators of the
+reference's native extension are registered under the same names in
+``torch.ops.torch_geometric_autoscale`` (csrc/async.cpp:44-48, csrc/relabel.cpp:40-42).
+"""
+import collections
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import REDUCE, check, lib
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _stream_of(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _rows_f32(t: Tensor, name: str, device=None) -> None:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D [rows, width], got {tuple(t.shape)}")
+    if t.size(1) > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name} must be row-major (unit stride along the width)")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+
+
+def _ld(t: Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
+
+
+def _need_cuda(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must live on the GPU: the aggregation and History-row kernels are HIP "
+            "only and there is no CPU implementation")
+
+
+# --------------------------------------------------------------------------- aggregation
+def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, n_cols: int,
+             reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
+             add_scale: float = 0.0, max_row_nnz: int = -1, out: Optional[Tensor] = None) -> Tensor:
+    """y = scale * reduce_rows(A, x) + add_scale * add   (incagg_spmm_csr_f32)."""
+    _need_cuda(x, "x")
+    dev = x.device
+    _rows_f32(x, "x")
+    n_rows = rowptr32.numel() - 1
+    if rowptr32.dtype != torch.int32 or col32.dtype != torch.int32:
+        raise TypeError("device CSR must be int32")
+    if rowptr32.device != dev or col32.device != dev or (val is not None and val.device != dev):
+        raise ValueError("CSR and x must be on the same device")
+    if val is not None and (val.dtype != torch.float32 or val.numel() != col32.numel()):
+        raise ValueError("val must be float32 with one entry per edge")
+    if x.size(0) < n_cols:
+        raise ValueError(f"x has {x.size(0)} rows but the adjacency has {n_cols} columns")
+    width = x.size(1)
+    if add is not None:
+        _rows_f32(add, "add", dev)
+        if add.size(0) < n_rows or add.size(1) != width:
+            raise ValueError("add must be [>= n_rows, width]")
+    if out is None:
+        out = torch.empty((n_rows, width), dtype=torch.float32, device=dev)
+    else:
+        _rows_f32(out, "out", dev)
+        if out.size(0) != n_rows or out.size(1) != width:
+            raise ValueError("out has the wrong shape")
+    with torch.cuda.device(dev):
+        check(lib().incagg_spmm_csr_f32(
+            _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), n_rows, n_cols, width,
+            REDUCE[reduce], float(scale), _ptr(add), 0 if add is None else _ld(add),
+            float(add_scale), int(max_row_nnz), _ptr(out), _ld(out), _stream_of(dev)))
+    return out
+
+
+def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor,
+                    m_in: Tensor, m_ag: Tensor, reduce: str = "sum", scale: float = 1.0,
+                    add: Optional[Tensor] = None, add_scale: float = 0.0, max_row_nnz: int = -1,
+                    out: Optional[Tensor] = None) -> Tensor:
+    """h = scale * (reduce_rows(A, x - m_in) + m_ag) + add_scale * add."""
+    _need_cuda(x, "x")
+    dev = x.device
+    n_rows = rowptr32.numel() - 1
+    width = x.size(1)
+    for t, name in ((x, "x"), (m_in, "m_in"), (m_ag, "m_ag")):
+        _rows_f32(t, name, dev)
+        if t.size(0) < n_rows or t.size(1) < width:
+            raise ValueError(f"{name} must be at least [{n_rows}, {width}], got {tuple(t.shape)}")
+    if rowptr32.dtype != torch.int32 or col32.dtype != torch.int32:
+        raise TypeError("device CSR must be int32")
+    if add is not None:
+        _rows_f32(add, "add", dev)
+        if add.size(0) < n_rows or add.size(1) != width:
+            raise ValueError("add must be [>= n_rows, width]")
+    if out is None:
+        out = torch.empty((n_rows, width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().incagg_spmm_csr_incagg_f32(
+            _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(m_in), _ld(m_in),
+            _ptr(m_ag), _ld(m_ag), n_rows, width, REDUCE[reduce], float(scale), _ptr(add),
+            0 if add is None else _ld(add), float(add_scale), int(max_row_nnz), _ptr(out), _ld(out),
+            _stream_of(dev)))
+    return out
+
+
+def rows_sub(a: Tensor, b: Tensor) -> Tensor:
+    _need_cuda(a, "a")
+    _rows_f32(a, "a")
+    _rows_f32(b, "b", a.device)
+    n, w = a.size(0), a.size(1)
+    if b.size(0) < n or b.size(1) < w:
+        raise ValueError("b is smaller than a")
+    out = torch.empty((n, w), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().incagg_rows_sub_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), n, w, _ptr(out), _ld(out),
+                                        _stream_of(a.device)))
+    return out
+
+
+# --------------------------------------------------------------------------- History rows
+def _device_visible(t: Tensor) -> bool:
+    return t.is_cuda or t.is_pinned()
+
+
+def gather_rows(emb: Tensor, n_id: Tensor, out: Optional[Tensor] = None,
+                device=None) -> Tensor:
+    """out[k] = emb[n_id[k]].  ``emb`` is HBM or pinned host memory; ``n_id`` on the GPU."""
+    _need_cuda(n_id, "n_id")
+    dev = n_id.device if device is None else torch.device(device)
+    _rows_f32(emb, "emb")
+    if not _device_visible(emb):
+        raise RuntimeError("emb must be on the GPU or in pinned host memory")
+    if emb.is_cuda and emb.device != dev:
+        raise ValueError("emb and n_id are on different GPUs")
+    if n_id.dtype != torch.int64 or n_id.dim() != 1 or not n_id.is_contiguous():
+        raise TypeError("n_id must be a contiguous 1-D int64 tensor")
+    k, w = n_id.numel(), emb.size(1)
+    if out is None:
+        out = torch.empty((k, w), dtype=torch.float32, device=dev)
+    else:
+        _rows_f32(out, "out", dev)
+        if out.size(0) < k or out.size(1) < w:
+            raise ValueError("out too small")
+    with torch.cuda.device(dev):
+        check(lib().incagg_gather_rows_f32(_ptr(emb), _ld(emb), emb.size(0), _ptr(n_id), k, w,
+                                           _ptr(out), _ld(out), _stream_of(dev)))
+    return out
+
+
+def scatter_rows(emb: Tensor, n_id: Tensor, x: Tensor) -> None:
+    """emb[n_id[k], :x.size(1)] = x[k]."""
+    _need_cuda(n_id, "n_id")
+    dev = n_id.device
+    _rows_f32(emb, "emb")
+    _rows_f32(x, "x", dev)
+    if not _device_visible(emb):
+        raise RuntimeError("emb must be on the GPU or in pinned host memory")
+    if n_id.dtype != torch.int64 or n_id.dim() != 1 or not n_id.is_contiguous():
+        raise TypeError("n_id must be a contiguous 1-D int64 tensor")
+    if x.size(0) != n_id.numel() or x.size(1) > emb.size(1):
+        raise ValueError("x must be [len(n_id), <= emb width]")
+    with torch.cuda.device(dev):
+        check(lib().incagg_scatter_rows_f32(_ptr(emb), _ld(emb), emb.size(0), _ptr(n_id),
+                                            n_id.numel(), x.size(1), _ptr(x), _ld(x),
+                                            _stream_of(dev)))
+
+
+def _host_i64(t: Tensor, name: str) -> Tensor:
+    if t.is_cuda:
+        raise RuntimeError(f"{name} tensor must be a CPU tensor")
+    if t.dim() != 1:
+        raise RuntimeError(f"{name} tensor must be one-dimensional")
+    return t.to(torch.int64).contiguous()
+
+
+def copy_row_chunks(dst: Tensor, src: Tensor, offset: Tensor, count: Tensor,
+                    packed_is_src: bool, device=None) -> None:
+    """Chunked row copy with zero padding (incagg_copy_row_chunks_f32)."""
+    _rows_f32(dst, "dst")
+    _rows_f32(src, "src")
+    if not (_device_visible(dst) and _device_visible(src)):
+        raise RuntimeError("both sides must be on the GPU or in pinned host memory")
+    dev = device or (dst.device if dst.is_cuda else src.device)
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise RuntimeError("at least one side must be on the GPU")
+    offset, count = _host_i64(offset, "Offset"), _host_i64(count, "Count")
+    if offset.numel() != count.numel():
+        raise RuntimeError("Size mismatch")
+    with torch.cuda.device(dev):
+        check(lib().incagg_copy_row_chunks_f32(
+            _ptr(dst), _ld(dst), dst.size(0), dst.size(1), _ptr(src), _ld(src), src.size(0),
+            src.size(1), _ptr(offset), _ptr(count), offset.numel(), 1 if packed_is_src else 0,
+            _stream_of(dev)))
+
+
+# --------------------------------------------------------------------------- batch construction
+def _relabel(fn, rowptr: Tensor, col: Tensor, value: Optional[Tensor], idx: Tensor,
+             bipartite: bool) -> Tuple[Tensor, Tensor, Optional[Tensor], Tensor]:
+    if rowptr.is_cuda:
+        raise RuntimeError("No GPU version supported: relabelling runs on the host")
+    if col.is_cuda:
+        raise RuntimeError("Col tensor must be a CPU tensor")
+    if idx.is_cuda:
+        raise RuntimeError("Index tensor must be a CPU tensor")
+    if value is not None:
+        if value.is_cuda:
+            raise RuntimeError("Value tensor must be a CPU tensor")
+        if value.dim() != 1:
+            raise RuntimeError("Value tensor must be one-dimensional")
+        value = value.contiguous()
+    for t, name in ((rowptr, "rowptr"), (col, "col"), (idx, "idx")):
+        if t.dtype != torch.int64:
+            raise RuntimeError(f"{name} must be int64")
+    rowptr, col, idx = rowptr.contiguous(), col.contiguous(), idx.contiguous()
+    n_nodes, n_idx = rowptr.numel() - 1, idx.numel()
+    ub = lib().incagg_relabel_bound(_ptr(rowptr), n_nodes, _ptr(idx), n_idx)
+    check(ub)
+    out_rowptr = torch.empty(2 * n_idx + 1 + ub, dtype=torch.int64)
+    out_col = torch.empty(ub, dtype=torch.int64)
+    out_n_id = torch.empty(n_idx + ub, dtype=torch.int64)
+    out_value = None if value is None else torch.empty(ub, dtype=value.dtype)
+    counts = torch.zeros(3, dtype=torch.int64)
+    check(fn(_ptr(rowptr), n_nodes, _ptr(col), _ptr(value),
+             0 if value is None else value.element_size(), _ptr(idx), n_idx, 1 if bipartite else 0,
+             out_rowptr.data_ptr(), _ptr(out_col), _ptr(out_value), _ptr(out_n_id),
+             counts.data_ptr()))
+    nnz, n_total, rp_len = counts.tolist()
+    return (out_rowptr[:rp_len].clone(), out_col[:nnz].clone(),
+            None if out_value is None else out_value[:nnz].clone(), out_n_id[:n_total].clone())
+
+
+def relabel_one_hop(rowptr, col, value, idx, bipartite):
+    """csrc/relabel.cpp:10-24."""
+    return _relabel(lib().incagg_relabel_one_hop, rowptr, col, value, idx, bipartite)
+
+
+def relabel_one_hop_within_batch(rowptr, col, value, idx, bipartite):
+    """csrc/relabel.cpp:27-38."""
+    return _relabel(lib().incagg_relabel_one_hop_within_batch, rowptr, col, value, idx, bipartite)
+
+
+def csr_transpose(rowptr: Tensor, col: Tensor, val: Optional[Tensor], n_rows: int, n_cols: int,
+                  reduce: str = "sum") -> Tuple[Tensor, Tensor, Tensor]:
+    """Host CSR (int64) -> transposed device-format CSR (int32, fp32 values), on the CPU."""
+    rowptr = rowptr.to("cpu", torch.int64).contiguous()
+    col = col.to("cpu", torch.int64).contiguous()
+    val = None if val is None else val.to("cpu", torch.float32).contiguous()
+    nnz = col.numel()
+    t_rowptr = torch.empty(n_cols + 1, dtype=torch.int32)
+    t_col = torch.empty(nnz, dtype=torch.int32)
+    t_val = torch.empty(nnz, dtype=torch.float32)
+    check(lib().incagg_csr_transpose(_ptr(rowptr), _ptr(col), _ptr(val), n_rows, n_cols,
+                                     REDUCE[reduce], t_rowptr.data_ptr(), _ptr(t_col), _ptr(t_val)))
+    return t_rowptr, t_col, t_val
+
+
+# --------------------------------------------------------------------------- staging
+# Tensors of queued reads are held here until the matching synchronize(), which is
+# what capturing them by value in the worker lambda does in the reference
+# (csrc/cuda/async_cuda.cu:63).
+_inflight_reads = collections.deque()
+
+
+def _non_default_stream(device) -> int:
+    cur = torch.cuda.current_stream(device)
+    if cur == torch.cuda.default_stream(device):
+        raise RuntimeError("Asynchronous read/write requires a non-default stream")
+    return cur.cuda_stream
+
+
+def read_async(src: Tensor, offset: Optional[Tensor], count: Optional[Tensor], index: Tensor,
+               dst: Tensor, buffer: Tensor) -> None:
+    """csrc/async.cpp:21-32 / csrc/cuda/async_cuda.cu:14-115."""
+    if src.is_cuda:
+        raise RuntimeError("Source tensor must be a CPU tensor")
+    if index.is_cuda:
+        raise RuntimeError("Index tensor must be a CPU tensor")
+    if not dst.is_cuda:
+        raise RuntimeError("Target tensor must be a GPU tensor")
+    if buffer.is_cuda:
+        raise RuntimeError("Buffer tensor must be a CPU tensor")
+    if not buffer.is_pinned():
+        raise RuntimeError("Buffer tensor must be pinned")
+    for t, name in ((src, "Source"), (dst, "Target"), (buffer, "Buffer")):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor must be contiguous")
+    if index.dim() != 1:
+        raise RuntimeError("Index tensor must be one-dimensional")
+    n_chunks = 0
+    if offset is not None:
+        if not src.is_pinned():
+            raise RuntimeError("Source tensor must be pinned")
+        if count is None:
+            raise RuntimeError("Count tensor is undefined")
+        offset, count = _host_i64(offset, "Offset"), _host_i64(count, "Count")
+        if offset.numel() != count.numel():
+            raise RuntimeError("Size mismatch")
+        n_chunks = offset.numel()
+    if index.numel() and index.dtype != torch.int64:
+        raise RuntimeError("Index tensor must be int64")
+    index = index.contiguous()
+    if src.dtype != dst.dtype or src.dtype != buffer.dtype:
+        raise RuntimeError("Source, target and buffer must share one dtype")
+    row_elems = src.numel() // max(src.size(0), 1)
+    if dst.numel() // max(dst.size(0), 1) != row_elems or \
+            buffer.numel() // max(buffer.size(0), 1) != row_elems:
+        raise RuntimeError("Source, target and buffer rows must have the same size")
+    stream = _non_default_stream(dst.device)
+    with torch.cuda.device(dst.device):
+        check(lib().incagg_stage_read_async(
+            _ptr(src), src.size(0), row_elems * src.element_size(), _ptr(offset), _ptr(count),
+            n_chunks, _ptr(index), index.numel(), _ptr(dst), dst.size(0), _ptr(buffer),
+            buffer.size(0), stream))
+    _inflight_reads.append((src, offset, count, index, dst, buffer))
+
+
+def synchronize() -> None:
+    """csrc/async.cpp:13-19: join exactly one queued read, oldest first."""
+    try:
+        check(lib().incagg_stage_synchronize())
+    finally:
+        if _inflight_reads:
+            _inflight_reads.popleft()
+
+
+def write_async(src: Tensor, offset: Tensor, count: Tensor, dst: Tensor) -> None:
+    """csrc/async.cpp:34-41 / csrc/cuda/async_cuda.cu:117-165."""
+    if not src.is_cuda:
+        raise RuntimeError("Source tensor must be a GPU tensor")
+    if dst.is_cuda:
+        raise RuntimeError("Target tensor must be a CPU tensor")
+    if not dst.is_pinned():
+        raise RuntimeError("Target tensor must be pinned")
+    if not src.is_contiguous():
+        raise RuntimeError("Source tensor must be contiguous")
+    if not dst.is_contiguous():
+        raise RuntimeError("Target tensor must be contiguous")
+    offset, count = _host_i64(offset, "Offset"), _host_i64(count, "Count")
+    if offset.numel() != count.numel():
+        raise RuntimeError("Size mismatch")
+    if src.dtype != dst.dtype:
+        raise RuntimeError("Source and target must share one dtype")
+    row_elems = src.numel() // max(src.size(0), 1)
+    if dst.numel() // max(dst.size(0), 1) != row_elems:
+        raise RuntimeError("Source and target rows must have the same size")
+    stream = _non_default_stream(src.device)
+    with torch.cuda.device(src.device):
+        check(lib().incagg_stage_write_async(
+            _ptr(src), src.size(0), row_elems * src.element_size(), _ptr(offset), _ptr(count),
+            offset.numel(), _ptr(dst), dst.size(0), stream))
+
+
+# --------------------------------------------------------------------------- torch.ops registration
+_registered = None
+
+
+def register_torch_ops() -> bool:
+    """Defines torch.ops.torch_geometric_autoscale.{synchronize, read_async, write_async,
+    relabel_one_hop, relabel_one_hop_within_batch} with the reference's schemas."""
+    global _registered
+    if _registered is not None:
+        return True
+    try:
+        reg = torch.library.Library("torch_geometric_autoscale", "DEF")
+    except RuntimeError:
+        return False  # namespace already defined by another library in this process
+    relabel_schema = ("(Tensor rowptr, Tensor col, Tensor? value, Tensor idx, bool bipartite)"
+                      " -> (Tensor, Tensor, Tensor?, Tensor)")
+    reg.define("synchronize() -> ()")
+    reg.define("read_async(Tensor src, Tensor? offset, Tensor? count, Tensor index, Tensor dst, "
+               "Tensor buffer) -> ()")
+    reg.define("write_async(Tensor src, Tensor offset, Tensor count, Tensor dst) -> ()")
+    reg.define("relabel_one_hop" + relabel_schema)
+    reg.define("relabel_one_hop_within_batch" + relabel_schema)
+    key = "CompositeExplicitAutograd"
+    reg.impl("synchronize", synchronize, key)
+    reg.impl("read_async", read_async, key)
+    reg.impl("write_async", write_async, key)
+    reg.impl("relabel_one_hop", relabel_one_hop, key)
+    reg.impl("relabel_one_hop_within_batch", relabel_one_hop_within_batch, key)
+    _registered = reg
+    return True
+
+
+__all__ = [
+    "spmm_csr", "spmm_csr_incagg", "rows_sub", "gather_rows", "scatter_rows", "copy_row_chunks",
+    "relabel_one_hop", "relabel_one_hop_within_batch", "csr_transpose", "read_async",
+    "write_async", "synchronize", "register_torch_ops",
+]

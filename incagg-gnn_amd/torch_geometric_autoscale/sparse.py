@@ -1,0 +1,296 @@
+"""A minimal CSR container with the part of the ``torch_sparse.SparseTensor`` surface the
+reference touches (loader.py:180-185, models/gcn.py:117-135, models/graphsage.py:631,
+main.py:62,148,182, metis.py:58, data.py:59, utils.py:62-73).
+
+On the host it holds int64 ``rowptr`` / ``col`` (the reference's layout).  On the GPU
+the primary storage is int32 (halves index traffic in the aggregation kernels); int64
+views are materialised only if somebody asks for them.  The transposed CSR needed by
+the backward aggregation is built once per adjacency and cached.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+class _Storage:
+    """``adj.storage.row() / col() / value() / rowptr() / rowcount()``."""
+
+    def __init__(self, owner: "SparseTensor"):
+        self._o = owner
+
+    def row(self) -> Tensor:
+        return self._o._coo_row()
+
+    def col(self) -> Tensor:
+        return self._o._col64()
+
+    def value(self) -> Optional[Tensor]:
+        return self._o._value
+
+    def rowptr(self) -> Tensor:
+        return self._o._rowptr64()
+
+    def rowcount(self) -> Tensor:
+        rp = self._o._rowptr64()
+        return rp[1:] - rp[:-1]
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self._o._sizes
+
+
+class SparseTensor:
+    def __init__(self, row: Optional[Tensor] = None, rowptr: Optional[Tensor] = None,
+                 col: Optional[Tensor] = None, value: Optional[Tensor] = None,
+                 sparse_sizes: Optional[Tuple[int, int]] = None, is_sorted: bool = False,
+                 trust_data: bool = False):
+        if col is None:
+            raise ValueError("col is required")
+        if rowptr is None and row is None:
+            raise ValueError("either row or rowptr is required")
+        col = col.to(torch.int64)
+        if rowptr is None:
+            row = row.to(torch.int64)
+            n_rows = sparse_sizes[0] if sparse_sizes is not None else (
+                int(row.max()) + 1 if row.numel() else 0)
+            if not is_sorted and row.numel():
+                n_c = (sparse_sizes[1] if sparse_sizes is not None else int(col.max()) + 1)
+                perm = torch.argsort(row * max(n_c, 1) + col, stable=True)
+                row, col = row[perm], col[perm]
+                value = None if value is None else value[perm]
+            rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=col.device)
+            if row.numel():
+                rowptr[1:] = torch.cumsum(torch.bincount(row, minlength=n_rows), 0)
+        else:
+            rowptr = rowptr.to(torch.int64)
+        n_rows = rowptr.numel() - 1
+        if sparse_sizes is None:
+            n_cols = int(col.max()) + 1 if col.numel() else 0
+            sparse_sizes = (n_rows, n_cols)
+        self._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        self._device = col.device
+        self._rowptr_i64: Optional[Tensor] = rowptr
+        self._col_i64: Optional[Tensor] = col
+        self._rowptr_i32: Optional[Tensor] = None
+        self._col_i32: Optional[Tensor] = None
+        self._value = value
+        self._row: Optional[Tensor] = None
+        self._host: Optional["SparseTensor"] = None   # CPU original of a GPU copy
+        self._transposed = {}                         # reduce -> (rowptr32, col32, val, max_nnz)
+        self._max_row_nnz: Optional[int] = None
+        self.storage = _Storage(self)
+
+    # ------------------------------------------------------------------ accessors
+    def _rowptr64(self) -> Tensor:
+        if self._rowptr_i64 is None:
+            self._rowptr_i64 = self._rowptr_i32.to(torch.int64)
+        return self._rowptr_i64
+
+    def _col64(self) -> Tensor:
+        if self._col_i64 is None:
+            self._col_i64 = self._col_i32.to(torch.int64)
+        return self._col_i64
+
+    def _rowptr32(self) -> Tensor:
+        if self._rowptr_i32 is None:
+            if self.nnz() >= 2 ** 31 - 1:
+                raise ValueError("adjacency too large for int32 device indices")
+            self._rowptr_i32 = self._rowptr_i64.to(torch.int32)
+        return self._rowptr_i32
+
+    def _col32(self) -> Tensor:
+        if self._col_i32 is None:
+            self._col_i32 = self._col_i64.to(torch.int32)
+        return self._col_i32
+
+    def _coo_row(self) -> Tensor:
+        if self._row is None:
+            rp = self._rowptr64()
+            self._row = torch.repeat_interleave(
+                torch.arange(self._sizes[0], device=rp.device), rp[1:] - rp[:-1])
+        return self._row
+
+    def csr(self) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        return self._rowptr64(), self._col64(), self._value
+
+    def coo(self) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        return self._coo_row(), self._col64(), self._value
+
+    def size(self, dim: int) -> int:
+        return self._sizes[dim]
+
+    def sizes(self):
+        return list(self._sizes)
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self._sizes
+
+    def sparse_size(self, dim: int) -> int:
+        return self._sizes[dim]
+
+    def nnz(self) -> int:
+        c = self._col_i64 if self._col_i64 is not None else self._col_i32
+        return int(c.numel())
+
+    def has_value(self) -> bool:
+        return self._value is not None
+
+    def device(self):
+        return self._device
+
+    def max_row_nnz(self) -> int:
+        if self._max_row_nnz is None:
+            if self._host is not None:
+                self._max_row_nnz = self._host.max_row_nnz()
+            else:
+                rc = self.storage.rowcount()
+                self._max_row_nnz = int(rc.max()) if rc.numel() else 0
+        return self._max_row_nnz
+
+    # ------------------------------------------------------------------ movement
+    def to(self, device=None, *args, non_blocking: bool = False, **kwargs) -> "SparseTensor":
+        if device is None or isinstance(device, torch.dtype):
+            return self
+        device = torch.device(device)
+        if device == self._device or (device.type == "cuda" and self._device.type == "cuda"
+                                       and device.index is None):
+            return self
+        if device.type == "cuda":
+            # Convert to the device format on the host, then upload 4-byte indices.
+            out = SparseTensor.__new__(SparseTensor)
+            out._sizes = self._sizes
+            out._device = device if device.index is not None else torch.device(
+                "cuda", torch.cuda.current_device())
+            out._rowptr_i64 = out._col_i64 = None
+            out._rowptr_i32 = self._rowptr32().to(out._device, non_blocking=non_blocking)
+            out._col_i32 = self._col32().to(out._device, non_blocking=non_blocking)
+            out._value = None if self._value is None else self._value.to(
+                out._device, non_blocking=non_blocking)
+            out._row = None
+            out._host = self if self._device.type == "cpu" else self._host
+            out._transposed = {}
+            out._max_row_nnz = self.max_row_nnz()
+            out.storage = _Storage(out)
+            return out
+        rowptr, col, value = self.csr()
+        out = SparseTensor(rowptr=rowptr.to(device), col=col.to(device),
+                           value=None if value is None else value.to(device),
+                           sparse_sizes=self._sizes, is_sorted=True)
+        return out
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    # ------------------------------------------------------------------ edits (host-side graph prep)
+    def set_value(self, value: Optional[Tensor], layout: Optional[str] = None) -> "SparseTensor":
+        out = SparseTensor.__new__(SparseTensor)
+        out.__dict__.update(self.__dict__)
+        out._value = value
+        out._transposed = {}
+        out._host = None if self._host is None else self._host.set_value(
+            None if value is None else value.cpu())
+        out.storage = _Storage(out)
+        return out
+
+    def set_value_(self, value: Optional[Tensor], layout: Optional[str] = None) -> "SparseTensor":
+        self._value = value
+        self._transposed = {}
+        if self._host is not None:
+            self._host = self._host.set_value(None if value is None else value.cpu())
+        return self
+
+    def set_diag(self, values: Optional[Tensor] = None) -> "SparseTensor":
+        """Replaces the diagonal by ones (or ``values``): main.py:148."""
+        row, col, value = self.coo()
+        n = min(self._sizes)
+        keep = row != col
+        diag = torch.arange(n, device=row.device)
+        new_row = torch.cat([row[keep], diag])
+        new_col = torch.cat([col[keep], diag])
+        new_val = None
+        if value is not None:
+            dv = torch.ones(n, dtype=value.dtype, device=value.device) if values is None else values
+            new_val = torch.cat([value[keep], dv])
+        return SparseTensor(row=new_row, col=new_col, value=new_val, sparse_sizes=self._sizes)
+
+    def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
+        return self.set_value(torch.full((self.nnz(),), fill, dtype=dtype, device=self._device))
+
+    def permute(self, perm: Tensor) -> "SparseTensor":
+        """Symmetric permutation: out[i, j] = self[perm[i], perm[j]] (metis.py:58)."""
+        row, col, value = self.coo()
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        return SparseTensor(row=inv[row], col=inv[col], value=value, sparse_sizes=self._sizes)
+
+    def t(self) -> "SparseTensor":
+        row, col, value = self.coo()
+        return SparseTensor(row=col, col=row, value=value,
+                            sparse_sizes=(self._sizes[1], self._sizes[0]))
+
+    def to_symmetric(self) -> "SparseTensor":
+        """Union with the transpose, duplicates merged (data.py:59)."""
+        row, col, value = self.coo()
+        n = max(self._sizes)
+        r = torch.cat([row, col])
+        c = torch.cat([col, row])
+        key = torch.unique(r * n + c)
+        if value is not None:
+            raise NotImplementedError("to_symmetric with values")
+        return SparseTensor(row=key // n, col=key % n, sparse_sizes=(n, n), is_sorted=True)
+
+    def masked_select_nnz(self, mask: Tensor, layout: Optional[str] = None) -> "SparseTensor":
+        row, col, value = self.coo()
+        return SparseTensor(row=row[mask], col=col[mask],
+                            value=None if value is None else value[mask],
+                            sparse_sizes=self._sizes, is_sorted=True)
+
+    def sum(self, dim: int) -> Tensor:
+        row, col, value = self.coo()
+        idx = row if dim == 1 else col
+        w = torch.ones(idx.numel(), device=idx.device) if value is None else value
+        return torch.zeros(self._sizes[1 - dim], dtype=w.dtype, device=w.device).index_add_(0, idx, w)
+
+    # ------------------------------------------------------------------ device-format views
+    def device_csr(self):
+        """(rowptr int32, col int32, value fp32 | None) on the GPU."""
+        if self._device.type != "cuda":
+            raise RuntimeError("aggregation runs on the GPU only: move the adjacency with .to(device)")
+        v = self._value
+        if v is not None and v.dtype != torch.float32:
+            v = v.to(torch.float32)
+        return self._rowptr32(), self._col32(), v
+
+    def device_csr_t(self, reduce: str = "sum"):
+        """Transposed CSR for dX = A^T dY, with 1/len(row) folded in for 'mean'."""
+        key = "mean" if reduce == "mean" else "sum"
+        if key not in self._transposed:
+            src = self._host if self._host is not None else self
+            rowptr, col, value = src.csr()
+            t_rowptr, t_col, t_val = ops.csr_transpose(rowptr, col, value, self._sizes[0],
+                                                       self._sizes[1], key)
+            cnt = t_rowptr[1:] - t_rowptr[:-1]
+            max_nnz = int(cnt.max()) if cnt.numel() else 0
+            dev = self._device
+            self._transposed[key] = (t_rowptr.to(dev), t_col.to(dev), t_val.to(dev), max_nnz)
+        return self._transposed[key]
+
+    # ------------------------------------------------------------------ aggregation
+    def matmul(self, other: Tensor, reduce: str = "sum") -> Tensor:
+        from .aggregate import spmm
+        return spmm(self, other, reduce)
+
+    def __matmul__(self, other: Tensor) -> Tensor:
+        return self.matmul(other, "sum")
+
+    def spmm(self, other: Tensor, reduce: str = "sum") -> Tensor:
+        return self.matmul(other, reduce)
+
+    def __repr__(self) -> str:
+        return (f"SparseTensor(sparse_sizes={self._sizes}, nnz={self.nnz()}, "
+                f"has_value={self._value is not None}, device={self._device})")

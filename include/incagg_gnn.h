@@ -1,0 +1,236 @@
+/*
+ * incagg_gnn.h -- C ABI of the MI355X (gfx950) hot-path library.
+ *
+ * One shared object, libincagg_gnn.so, exports everything below with C linkage,
+ * plain pointers and sizes; no framework types cross this boundary.  Each entry
+ * point names the reference interface it stands in for (paths are relative to the
+ * reference tree).
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative INCAGG_E_* code on
+ *     failure; incagg_last_error() then holds a message for the calling thread.
+ *   - "device pointer" = memory the GPU can address (HBM, or host memory pinned
+ *     with hipHostMalloc / hipHostRegister, which gfx950 reads over the host link).
+ *   - `stream` is a hipStream_t passed as void*; NULL is the default stream.
+ *     Kernel entry points only enqueue work; they never synchronise.
+ *   - Matrices are fp32, row-major, with a leading dimension given in ELEMENTS.
+ *   - Device-side CSR uses int32 row pointers and column ids; the int64 forms of
+ *     the reference's Python API are converted when a batch is uploaded.
+ */
+#ifndef INCAGG_GNN_H
+#define INCAGG_GNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INCAGG_ABI_VERSION 1
+
+enum {
+  INCAGG_OK = 0,
+  INCAGG_E_INVALID = -1,   /* bad argument (shape, size, alignment, null) */
+  INCAGG_E_HIP = -2,       /* a HIP runtime call failed */
+  INCAGG_E_NOMEM = -3,     /* host allocation failed */
+  INCAGG_E_INDEX = -4,     /* an index was outside its table */
+  INCAGG_E_NODEVICE = -5   /* no usable GPU */
+};
+
+enum { INCAGG_REDUCE_SUM = 0, INCAGG_REDUCE_MEAN = 1 };
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char *incagg_last_error(void);
+int incagg_abi_version(void);
+
+/* Number of visible GPUs (0 when there is none); never fails. */
+int incagg_device_count(void);
+
+/*
+ * Kernels skip any row / column id that is outside its table instead of
+ * faulting and latch a flag on the device.  This call reads and clears the flag
+ * of the current device: returns 0 if clean, INCAGG_E_INDEX if a kernel since
+ * the last call saw a bad index.  It synchronises the device.
+ */
+int incagg_check_device_errors(void);
+
+/* ------------------------------------------------------------------ aggregation
+ * y[i,:] = scale * reduce_{e in row i} val[e] * x[col[e],:]  +  add_scale * add[i,:]
+ *
+ * Stands in for every `adj_t @ x`, `spmm(adj_t, x, reduce)` and conv.propagate of
+ * the reference (models/appnp.py:85,89,152; models/gcn.py:143,164,296,361,386,403;
+ * models/gcn2.py:130,142,336,454,477,499; models/graphsage.py:187,272,727,898,928,952),
+ * with the APPNP / GCNII mix `(1-alpha)*(A x) + alpha*x_0` (models/appnp.py:85)
+ * folded into the epilogue.  The backward pass dX = A^T dY is the same call on
+ * the transposed CSR (see incagg_csr_transpose).
+ *
+ *   rowptr[n_rows+1], col[nnz]  device int32;  val[nnz] device fp32 or NULL (= 1)
+ *   x[n_cols, width]  ld = ldx;  add (may be NULL) [n_rows, width] ld = ldadd
+ *   reduce: INCAGG_REDUCE_SUM | INCAGG_REDUCE_MEAN (divide by max(row length, 1))
+ *   max_row_nnz: length of the longest row if the caller knows it, else -1.
+ *   y[n_rows, width] ld = ldy; must not alias x.
+ *   width <= 1024 when every pointer is 16-byte aligned and every ld a multiple
+ *   of 4, else width <= 256.
+ *
+ * Rows longer than 512 edges are cut into 256-edge slices that are summed onto
+ * the row with fp32 atomics by a second launch (skipped when max_row_nnz says
+ * there is no such row), so such rows are reproducible only up to fp32 rounding
+ * order.  The slice queue is device memory the library allocates once per
+ * (device, stream) on the first call that may need it.
+ */
+int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                        const float *x, int64_t ldx, int64_t n_rows, int64_t n_cols,
+                        int64_t width, int reduce, float scale, const float *add,
+                        int64_t ldadd, float add_scale, int64_t max_row_nnz, float *y,
+                        int64_t ldy, void *stream);
+
+/*
+ * Fused incremental aggregate (the fork's contribution):
+ *   h[i,:] = scale * ( reduce_{e in row i} val[e] * (x[c,:] - m_in[c,:]) + m_ag[i,:] )
+ *            + add_scale * add[i,:],          c = col[e]
+ * Stands in for `adj_t @ (x - M_in) + M_ag` (models/gcn.py:241,262;
+ * models/gcn2.py:255,305; models/appnp.py:122,130; models/graphsage.py:634,683)
+ * including the two `.clone()`s of the pulled tiles that precede it there.
+ * The CSR is n_rows x n_rows (in-batch edges only).
+ */
+int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                               const float *x, int64_t ldx, const float *m_in,
+                               int64_t ldin, const float *m_ag, int64_t ldag,
+                               int64_t n_rows, int64_t width, int reduce, float scale,
+                               const float *add, int64_t ldadd, float add_scale,
+                               int64_t max_row_nnz, float *h, int64_t ldh, void *stream);
+
+/* d[i,:] = a[i,:] - b[i,:] over [n_rows, width]; the unfused first step of the
+ * incremental aggregate (`x - M_in`, models/gcn2.py:255). */
+int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, int64_t ldb,
+                        int64_t n_rows, int64_t width, float *d, int64_t ldd,
+                        void *stream);
+
+/* ------------------------------------------------------------------ History rows
+ * out[k,:] = emb[n_id[k],:]            (History.pull, history.py:33-39; the
+ * gathered half of read_async, csrc/cuda/async_cuda.cu:95-110).
+ * n_id: device int64[k_rows].  emb may be pinned host memory (zero-copy pull).
+ */
+int incagg_gather_rows_f32(const float *emb, int64_t lde, int64_t emb_rows,
+                           const int64_t *n_id, int64_t k_rows, int64_t width,
+                           float *out, int64_t ldo, void *stream);
+
+/* emb[n_id[k], :width] = x[k, :width]  (History.push by index, history.py:53-58).
+ * Indices are expected to be unique; with duplicates one of the rows wins. */
+int incagg_scatter_rows_f32(float *emb, int64_t lde, int64_t emb_rows,
+                            const int64_t *n_id, int64_t k_rows, int64_t width,
+                            const float *x, int64_t ldx, void *stream);
+
+/*
+ * Chunked row copy, both directions of the reference's contiguous-chunk traffic:
+ *   push: dst[dst_off[c] + r, :] = src[s + r, :]   with s advancing by count[c]
+ *         (History.push by chunks, history.py:60-65; write_async,
+ *          csrc/cuda/async_cuda.cu:139-163)
+ *   pull: dst[s + r, :] = src[src_off[c] + r, :]   (read_async chunks,
+ *          csrc/cuda/async_cuda.cu:68-92)
+ * `packed_is_src` != 0 selects push (the packed side is the source).
+ * offset[], count[] are HOST int64 arrays of n_chunks entries (as in the
+ * reference's API); they are consumed before the call returns.
+ * Columns [src_width, dst_width) of every written row are zero-filled, which is
+ * the zero-padding to the table width done in models/gcn.py:355-365,
+ * models/graphsage.py:888-902, models/appnp.py:254-265.
+ */
+int incagg_copy_row_chunks_f32(float *dst, int64_t ldd, int64_t dst_rows, int64_t dst_width,
+                               const float *src, int64_t lds, int64_t src_rows,
+                               int64_t src_width, const int64_t *offset,
+                               const int64_t *count, int64_t n_chunks, int packed_is_src,
+                               void *stream);
+
+/* ------------------------------------------------------------------ host <-> HBM staging
+ * One process-wide worker thread runs queued reads in FIFO order
+ * (csrc/thread.h:10-69, csrc/cuda/async_cuda.cu:7-12).
+ *
+ * incagg_stage_read_async  == read_async  (csrc/async.cpp:21-32, async_cuda.cu:14-115)
+ *   On the worker: for every chunk, an H2D hipMemcpyAsync of count[c] rows from
+ *   src_host + offset[c] to consecutive rows of dst_dev; then, if n_index > 0, the
+ *   rows src_host[index[.]] are gathered on the host into `bounce_host` (pinned)
+ *   and copied behind the chunks.  All copies go to `stream`.
+ *   Preconditions as the reference asserts them (async_cuda.cu:20-59):
+ *   sum(count) + n_index <= bounce_rows and <= dst_rows; chunks inside src;
+ *   a non-default stream.  offset/count are copied; `index` must stay valid until
+ *   the matching incagg_stage_synchronize() returns.
+ *   Unlike the reference it does NOT block the caller on the stream, and copy
+ *   errors are reported by incagg_stage_synchronize() instead of being printed.
+ *
+ * incagg_stage_synchronize == synchronize (csrc/async.cpp:13-19, thread.h:64-69)
+ *   Joins exactly ONE queued read, oldest first; no-op when none is queued.
+ *   Returns that task's status.  The data is on the device once `stream` has
+ *   also been synchronised (pool.py:86-87).
+ *
+ * incagg_stage_write_async == write_async (csrc/async.cpp:34-41, async_cuda.cu:117-165)
+ *   On the caller's thread: for every chunk a D2H hipMemcpyAsync of count[c] rows
+ *   from consecutive rows of src_dev to dst_host + offset[c].  Does not block.
+ */
+int incagg_stage_read_async(const void *src_host, int64_t src_rows, int64_t row_bytes,
+                            const int64_t *offset, const int64_t *count, int64_t n_chunks,
+                            const int64_t *index, int64_t n_index, void *dst_dev,
+                            int64_t dst_rows, void *bounce_host, int64_t bounce_rows,
+                            void *stream);
+int incagg_stage_synchronize(void);
+int incagg_stage_write_async(const void *src_dev, int64_t src_rows, int64_t row_bytes,
+                             const int64_t *offset, const int64_t *count, int64_t n_chunks,
+                             void *dst_host, int64_t dst_rows, void *stream);
+/* Number of reads queued and not yet joined (test / debugging aid). */
+int64_t incagg_stage_pending(void);
+
+/* ------------------------------------------------------------------ batch construction (host)
+ * Sum of the degrees of idx[]: the capacity the relabel outputs need.
+ * Returns < 0 if an index is outside [0, n_nodes). */
+int64_t incagg_relabel_bound(const int64_t *rowptr, int64_t n_nodes, const int64_t *idx,
+                             int64_t n_idx);
+
+/*
+ * relabel_one_hop (csrc/relabel.cpp:10-24, csrc/cpu/relabel_cpu.cpp:3-108).
+ * From the global CSR and the in-batch ids idx[], builds the local CSR whose rows
+ * are idx[] in order and whose columns are local ids: position in idx[] for
+ * in-batch neighbours (a duplicated id maps to its LAST position), otherwise
+ * n_idx + k with k counting out-of-batch neighbours in first-seen edge order.
+ * `value` (may be NULL) holds nnz items of value_size bytes, copied verbatim.
+ * Caller-provided outputs, with ub = incagg_relabel_bound(...):
+ *   out_rowptr[n_idx + 1 + ub], out_col[ub], out_value[ub * value_size],
+ *   out_n_id[n_idx + ub]
+ * counts[0] = nnz, counts[1] = len(out_n_id), counts[2] = len(out_rowptr)
+ * (out_rowptr gains one trailing `nnz` per out-of-batch id when !bipartite).
+ */
+int incagg_relabel_one_hop(const int64_t *rowptr, int64_t n_nodes, const int64_t *col,
+                           const void *value, int64_t value_size, const int64_t *idx,
+                           int64_t n_idx, int bipartite, int64_t *out_rowptr,
+                           int64_t *out_col, void *out_value, int64_t *out_n_id,
+                           int64_t *counts);
+
+/*
+ * relabel_one_hop_within_batch (csrc/relabel.cpp:27-38, relabel_cpu.cpp:111-214):
+ * same, keeping only edges whose neighbour is in idx[]; out_n_id = idx.
+ * out_rowptr needs 2 * n_idx + 1 entries (when !bipartite it gains one trailing
+ * `nnz` per DISTINCT id of idx[]).
+ */
+int incagg_relabel_one_hop_within_batch(const int64_t *rowptr, int64_t n_nodes,
+                                        const int64_t *col, const void *value,
+                                        int64_t value_size, const int64_t *idx,
+                                        int64_t n_idx, int bipartite, int64_t *out_rowptr,
+                                        int64_t *out_col, void *out_value,
+                                        int64_t *out_n_id, int64_t *counts);
+
+/*
+ * Host-side CSR -> device-format transposed CSR, built once per batch so that the
+ * backward pass dX = A^T dY (autograd through every aggregation call site,
+ * main.py:81) is a plain row-parallel aggregation without atomics.
+ *   in : rowptr[n_rows+1], col[nnz] int64; val[nnz] fp32 or NULL
+ *   out: t_rowptr[n_cols+1], t_col[nnz] int32 (t_col = source row id, ascending
+ *        inside every transposed row), t_val[nnz] fp32 = val (or 1), divided by
+ *        max(len(row), 1) when reduce == INCAGG_REDUCE_MEAN.
+ */
+int incagg_csr_transpose(const int64_t *rowptr, const int64_t *col, const float *val,
+                         int64_t n_rows, int64_t n_cols, int reduce, int32_t *t_rowptr,
+                         int32_t *t_col, float *t_val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCAGG_GNN_H */
