@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Headline benchmark: edges aggregated per second of GCNII push/pull training steps on an
+ogbn-products-sized partitioned graph (BASELINE.json configs[2]: GCN2, 150 parts, 8 layers,
+hidden 256), one process per GPU.
+
+A step = one partition batch through the hot path: 8 x (HIP CSR aggregation over the
+batch's [B, M] one-hop adjacency, push of the B fresh rows into the next layer's History
+table, pull of the M - B out-of-batch rows), the dense GCNII updates, the loss, the
+backward pass (8 transposed aggregations) and the Adam step.  Inputs (graph, features,
+History tables) are resident in HBM before the timed region.  `value` counts every edge
+of every aggregation, forward and backward: 2 * L * nnz(adj_t) per step.
+
+Prints ONE JSON line (rank 0).  Data is synthetic: a seeded power-law graph with the
+public ogbn-products statistics planted in 150 communities (no dataset download).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "incagg-gnn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dataset", default="products")
+    ap.add_argument("--parts", type=int, default=150)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink nodes and edges together")
+    ap.add_argument("--cross", type=float, default=0.15, help="fraction of inter-community edges")
+    ap.add_argument("--mode", default="gas", choices=["gas", "vr"],
+                    help="push/pull training step (headline) or incremental-aggregation step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+class KernelClock:
+    """HIP-event timing of every aggregation launch inside the timed region, on the stream
+    the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []   # (start, end, algorithmic_bytes, gather_bytes, edges)
+        self.enabled = False
+
+    def wrap(self, ops):
+        inner = ops.spmm_csr
+        clock = self
+
+        def timed(rowptr32, col32, val, x, n_cols, *a, **k):
+            if not clock.enabled:
+                return inner(rowptr32, col32, val, x, n_cols, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = inner(rowptr32, col32, val, x, n_cols, *a, **k)
+            e.record()
+            n_rows, nnz, f = rowptr32.numel() - 1, col32.numel(), x.size(1)
+            # compulsory traffic: indices + weights, row pointers, every distinct source row
+            # once, every destination row once (source rows touched <= n_cols)
+            algo = nnz * (4 + (4 if val is not None else 0)) + (n_rows + 1) * 4 \
+                + min(n_cols, nnz) * f * 4 + n_rows * f * 4
+            gather = nnz * (f * 4 + 8) + n_rows * f * 4
+            clock.records.append((s, e, algo, gather, nnz))
+            return y
+
+        ops.spmm_csr = timed
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = [s.elapsed_time(e) for s, e, *_ in self.records]
+        algo = sum(r[2] for r in self.records)
+        gather = sum(r[3] for r in self.records)
+        tot_s = sum(ms) / 1e3
+        return {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "algo_GBps": algo / tot_s / 1e9,
+                "gather_GBps": gather / tot_s / 1e9,
+                "algo_bytes_per_launch": algo / len(ms)}
+
+
+def cpu_baseline(batches, layers, width, seconds):
+    """The CPU oracle's aggregation (forward + transposed) on the same batches, all host
+    cores the box grants (OMP), for about `seconds` of work."""
+    from oracle import cpu_path as cp
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    cp.set_threads(cores)
+    rng = np.random.default_rng(1)
+    edges, t_total, used = 0, 0.0, 0
+    for rowptr, col, val, m in batches:
+        b = rowptr.size - 1
+        x = rng.standard_normal((m, width)).astype(np.float32)
+        dy = rng.standard_normal((b, width)).astype(np.float32)
+        # transposed CSR for the backward aggregation (built outside the timed part)
+        order = np.argsort(col, kind="stable")
+        t_col = np.repeat(np.arange(b), np.diff(rowptr))[order].astype(np.int64)
+        t_val = val[order]
+        t_rowptr = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(np.bincount(col, minlength=m), out=t_rowptr[1:])
+        cp.spmm(rowptr, col, val, x)  # warm
+        t0 = time.perf_counter()
+        for _ in range(layers):
+            cp.spmm(rowptr, col, val, x)
+            cp.spmm(t_rowptr, t_col, t_val, dy)
+        t_total += time.perf_counter() - t0
+        edges += 2 * layers * col.size
+        used += 1
+        if t_total >= seconds:
+            break
+    return {"value": edges / t_total, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"forward + transposed fp32 CSR aggregation of {used} partition batch(es) x "
+                      f"{layers} layers at width {width} (dense updates, push/pull and optimizer "
+                      f"not included), C/OpenMP oracle, {t_total:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch_geometric_autoscale as tga
+    from torch_geometric_autoscale import ops, _lib
+    from torch_geometric_autoscale.models import GCN2
+    from torch_geometric_autoscale.loader import partition_batch
+
+    clock = KernelClock()
+    clock.wrap(ops)
+
+    t_setup = time.perf_counter()
+    data, f_in, n_cls = tga.get_data(None, args.dataset, num_parts=args.parts, scale=args.scale,
+                                     cross_fraction=args.cross, seed=0, features=False, device=dev,
+                                     keep_on_device=True)
+    n = data.num_nodes
+    # self loops + symmetric normalisation on the GPU (main.py:147-151), then to the host,
+    # where batches are built
+    data.adj_t = tga.gcn_norm(data.adj_t.set_diag()).to("cpu")
+    torch.cuda.empty_cache()
+    ptr = data.ptr
+    g = torch.Generator(device=dev).manual_seed(1)
+    x_all = torch.randn(n, f_in, device=dev, generator=g)   # features live in HBM
+    y_all = torch.randint(0, n_cls, (n,), device=dev, generator=g)
+
+    # partitions owned by this rank (contiguous block of parts => contiguous History rows)
+    parts_lo, parts_hi = rank * args.parts // world, (rank + 1) * args.parts // world
+    my_parts = list(range(parts_lo, parts_hi))
+    need = min(len(my_parts), args.steps + args.warmup)
+    loader_data = tga.Data(adj_t=data.adj_t, num_nodes=n)
+    batches = []
+    for p in my_parts[:need]:
+        sub = partition_batch(loader_data, ptr, [p], in_batch_only=(args.mode == "vr"))
+        adj = sub.data.adj_t.to(dev)
+        adj.device_csr_t("sum")                    # backward CSR, once per batch
+        nid_dev = sub.n_id.to(dev)
+        batches.append({
+            "adj": adj, "host": sub.data.adj_t, "b": sub.batch_size, "n_id": sub.n_id,
+            "nid_dev": nid_dev, "offset": sub.offset, "count": sub.count,
+            "x": x_all[nid_dev], "y": y_all[nid_dev[:sub.batch_size]],
+        })
+
+    model = GCN2(n, f_in, args.hidden, n_cls, args.layers, alpha=0.1, theta=0.5,
+                 shared_weights=False, dropout=0.0, device=dev).to(dev)
+    g_cpu = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if p_.dim() > 1:
+                p_.copy_((torch.rand(p_.shape, generator=g_cpu) * 2 - 1) *
+                         (6.0 / (p_.size(0) + p_.size(1))) ** 0.5)
+        for tables in (model.histories, model.histories_ag):   # non-trivial table contents
+            for h in tables:
+                h.emb.normal_(0, 0.1, generator=g)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    model.train()
+    setup_s = time.perf_counter() - t_setup
+
+    def step(i):
+        bt = batches[i % len(batches)]
+        if args.mode == "vr":
+            out = model.VR_call(bt["x"], bt["adj"], bt["b"], bt["nid_dev"], bt["offset"],
+                                bt["count"])["out"]
+        else:
+            out = model(bt["x"], bt["adj"], bt["b"], bt["nid_dev"], bt["offset"], bt["count"])["out"]
+        opt.zero_grad(set_to_none=True)
+        loss = crit(out, bt["y"])
+        loss.backward()
+        opt.step()
+        return 2 * args.layers * bt["adj"].nnz()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    clock.enabled = True
+    t0 = time.perf_counter()
+    edges = 0
+    for i in range(args.steps):
+        edges += step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    clock.enabled = False
+    _lib.check_device_errors()
+
+    tot = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
+    if world > 1:
+        t_max = tot[:1].clone()
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        e_sum = tot[1:].clone()
+        dist.all_reduce(e_sum, op=dist.ReduceOp.SUM)
+        elapsed, edges = float(t_max), float(e_sum)
+
+    ks = clock.summary()
+    if rank == 0:
+        bt = batches[0]
+        line = {
+            "metric": "edges-aggregated/sec, ogbn-products GCN2 training step (forward + backward)",
+            "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"GCN2 {args.layers}-layer hidden {args.hidden} on an ogbn-{args.dataset}-"
+                            f"sized synthetic graph (N={n}, nnz={data.adj_t.nnz()}), {args.parts} "
+                            f"partitions, one partition per step, {args.mode} training step, "
+                            "History tables resident in HBM",
+                "batch_rows": bt["b"], "batch_rows_with_halo": int(bt["n_id"].numel()),
+                "batch_edges": bt["adj"].nnz(), "parallelism": f"partition-parallel x{world}",
+                "setup_seconds": round(setup_s, 1),
+            },
+        }
+        if ks:
+            line["roofline"] = {
+                "bound": "hbm", "achieved": ks["algo_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ks["algo_GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "spmm_rows_kernel (+ spmm_hub_kernel), forward and transposed launches",
+                "avg_launch_ms": ks["avg_ms"], "launches": ks["launches"],
+                "algorithmic_bytes_per_launch": ks["algo_bytes_per_launch"],
+                "gather_bound_GBps": ks["gather_GBps"],
+            }
+        if not args.no_cpu_baseline:
+            host = []
+            for b_ in batches[:4]:
+                rp, c, v = b_["host"].csr()
+                host.append((rp.numpy(), c.numpy(), v.numpy().astype(np.float32),
+                             int(b_["n_id"].numel())))
+            line["cpu_baseline"] = cpu_baseline(host, args.layers, args.hidden, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

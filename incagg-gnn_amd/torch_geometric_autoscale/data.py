@@ -7,7 +7,6 @@ communities so that a partition-contiguous ``(perm, ptr)`` exists by constructio
 """
 from typing import Dict, Iterator, Optional, Tuple
 
-import numpy as np
 import torch
 from torch import Tensor
 
@@ -80,49 +79,63 @@ DATASET_STATS: Dict[str, Tuple[int, int, int, int]] = {
 
 
 def synthetic_graph(num_nodes: int, num_edges: int, num_parts: int, cross_fraction: float = 0.15,
-                    exponent: float = 2.1, seed: int = 0,
-                    max_degree_fraction: float = 0.02) -> Tuple[SparseTensor, Tensor]:
+                    exponent: float = 2.1, seed: int = 0, max_degree_fraction: float = 0.02,
+                    device="cpu", keep_on_device: bool = False) -> Tuple[SparseTensor, Tensor]:
     """Symmetric power-law graph planted in ``num_parts`` contiguous communities.
 
-    Returns ``(adj_t, ptr)``: a value-less CSR without self loops or duplicates, and
-    ``ptr[num_parts + 1]`` community boundaries (part ``p`` owns ids ``[ptr[p], ptr[p+1])``,
-    the contract of metis.py:32-33 after ``permute``).  ``cross_fraction`` of the
-    edge endpoints leave their community.  Chung-Lu style: endpoints are drawn with
-    probability proportional to a power-law weight.
+    Returns ``(adj_t, ptr)`` (on the host unless ``keep_on_device``): a value-less CSR without self loops or
+    duplicates, and ``ptr[num_parts + 1]`` community boundaries (part ``p`` owns ids
+    ``[ptr[p], ptr[p+1])``, the contract of metis.py:32-33 after ``permute``).
+    Chung-Lu style: both endpoints of an edge are drawn with probability proportional to
+    a power-law node weight; ``cross_fraction`` of the edges may leave the source's
+    community.  ``device`` only selects where the sampling runs (a GPU makes the
+    124M-edge ogbn-products-sized graph a matter of seconds); the random stream, and so
+    the graph, depends on it.
     """
-    rng = np.random.default_rng(seed)
-    bounds = np.linspace(0, num_nodes, num_parts + 1).astype(np.int64)
-    part_of = np.repeat(np.arange(num_parts), np.diff(bounds))
-    # power-law expected degrees, capped so that one hub cannot dominate tiny graphs
-    w = (rng.pareto(exponent - 1.0, size=num_nodes) + 1.0)
-    w = np.minimum(w, max(4.0, max_degree_fraction * num_nodes))
+    device = torch.device(device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = num_nodes
+
+    def rand(k):
+        return torch.rand(k, generator=g, device=device, dtype=torch.float64)
+
+    bounds = (torch.arange(num_parts + 1, device=device, dtype=torch.int64) * n) // num_parts
+    part_of = torch.repeat_interleave(torch.arange(num_parts, device=device), bounds[1:] - bounds[:-1])
+    w = (1.0 - rand(n)).clamp_min(1e-12).pow(-1.0 / (exponent - 1.0))
+    w = w.clamp(max=max(4.0, max_degree_fraction * n))
+    cdf = torch.cumsum(w, 0)
+    total = cdf[-1]
+    def draw(half):
+        src = torch.searchsorted(cdf, rand(half) * total).clamp(max=n - 1)
+        cross = rand(half) < cross_fraction
+        dst_any = torch.searchsorted(cdf, rand(half) * total).clamp(max=n - 1)
+        p = part_of[src]
+        lo, hi = bounds[p], bounds[p + 1]
+        base = torch.where(lo > 0, cdf[(lo - 1).clamp(min=0)], torch.zeros_like(total))
+        target = base + rand(half) * (cdf[hi - 1] - base)
+        dst_local = torch.minimum(torch.maximum(torch.searchsorted(cdf, target), lo), hi - 1)
+        dst = torch.where(cross, dst_any, dst_local)
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+        return torch.unique(torch.cat([src * n + dst, dst * n + src]))
+
+    # Duplicate draws (frequent between heavy nodes) are merged, so draw more pairs
+    # until the de-duplicated edge count reaches the requested one.
     half = num_edges // 2
-    # source endpoints ~ w (global)
-    cdf = np.cumsum(w)
-    src = np.searchsorted(cdf, rng.random(half) * cdf[-1]).astype(np.int64)
-    src = np.minimum(src, num_nodes - 1)
-    # destination: inside the source's community (by local weight) or anywhere
-    cross = rng.random(half) < cross_fraction
-    dst = np.empty(half, dtype=np.int64)
-    dst_cross = np.searchsorted(cdf, rng.random(int(cross.sum())) * cdf[-1])
-    dst[cross] = np.minimum(dst_cross, num_nodes - 1)
-    p = part_of[src[~cross]]
-    lo, hi = bounds[p], bounds[p + 1]
-    base = np.where(lo > 0, cdf[np.maximum(lo - 1, 0)], 0.0)
-    top = cdf[hi - 1]
-    target = base + rng.random(p.size) * (top - base)
-    dst[~cross] = np.clip(np.searchsorted(cdf, target), lo, hi - 1)
-    keep = src != dst
-    src, dst = src[keep], dst[keep]
-    r = np.concatenate([src, dst])
-    c = np.concatenate([dst, src])
-    key = np.unique(r * num_nodes + c)
-    r, c = key // num_nodes, key % num_nodes
-    rowptr = np.zeros(num_nodes + 1, dtype=np.int64)
-    np.cumsum(np.bincount(r, minlength=num_nodes), out=rowptr[1:])
-    adj_t = SparseTensor(rowptr=torch.from_numpy(rowptr), col=torch.from_numpy(c.astype(np.int64)),
-                         sparse_sizes=(num_nodes, num_nodes), is_sorted=True)
-    return adj_t, torch.from_numpy(bounds)
+    key = draw(half)
+    for _ in range(3):
+        if key.numel() >= 0.97 * num_edges:
+            break
+        half = int(half * (num_edges / max(key.numel(), 1)) ** 1.25) + 1
+        key = draw(half)
+    row = torch.div(key, n, rounding_mode="floor")
+    col = key - row * n
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0)
+    if not keep_on_device:
+        rowptr, col = rowptr.cpu(), col.cpu()
+    adj_t = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n), is_sorted=True)
+    return adj_t, bounds.cpu()
 
 
 def gcn_norm(adj_t: SparseTensor, add_self_loops: bool = False) -> SparseTensor:
@@ -132,14 +145,15 @@ def gcn_norm(adj_t: SparseTensor, add_self_loops: bool = False) -> SparseTensor:
     if not adj_t.has_value():
         adj_t = adj_t.fill_value(1.0)
     row, col, value = adj_t.coo()
-    deg = torch.zeros(adj_t.size(0), dtype=value.dtype).index_add_(0, row, value)
+    deg = torch.zeros(adj_t.size(0), dtype=value.dtype, device=value.device).index_add_(0, row, value)
     dis = deg.pow(-0.5)
     dis[dis == float('inf')] = 0
     return adj_t.set_value(dis[row] * value * dis[col])
 
 
 def get_data(root: Optional[str], name: str, num_parts: int = 16, scale: float = 1.0,
-             cross_fraction: float = 0.15, seed: int = 0, features: bool = True):
+             cross_fraction: float = 0.15, seed: int = 0, features: bool = True, device="cpu",
+             keep_on_device: bool = False):
     """``(data, in_channels, out_channels)`` like data.py:118-145, on a synthetic graph with
     the named dataset's statistics (``scale`` shrinks nodes and edges together).
     ``data.ptr`` holds the planted partition boundaries."""
@@ -148,7 +162,8 @@ def get_data(root: Optional[str], name: str, num_parts: int = 16, scale: float =
         raise NotImplementedError(f"unknown dataset '{name}'")
     n, e, f_in, n_cls = DATASET_STATS[key]
     n, e = max(int(n * scale), num_parts * 4), max(int(e * scale), num_parts * 8)
-    adj_t, ptr = synthetic_graph(n, e, num_parts, cross_fraction, seed=seed)
+    adj_t, ptr = synthetic_graph(n, e, num_parts, cross_fraction, seed=seed, device=device,
+                                 keep_on_device=keep_on_device)
     g = torch.Generator().manual_seed(seed + 1)
     data = Data(adj_t=adj_t, num_nodes=n, ptr=ptr)
     if features:

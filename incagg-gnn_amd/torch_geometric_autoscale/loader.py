@@ -56,6 +56,29 @@ def sample_neighbors(src: SparseTensor, num_neighbors: int,
     return out, unsampled_n_id
 
 
+def partition_batch(data: Data, ptr: Tensor, part_ids, in_batch_only: bool = False,
+                    bipartite: bool = True) -> SubData:
+    """The batch made of the partitions ``part_ids`` (ids into ``ptr``): their rows, and
+    unless ``in_batch_only`` their one-hop halo.  What the loaders' collate functions
+    produce, callable directly."""
+    part_ids = [int(p) for p in part_ids]
+    n_id = torch.cat([torch.arange(int(ptr[p]), int(ptr[p + 1])) for p in part_ids])
+    batch_id = torch.tensor(part_ids)
+    offset = ptr[batch_id]
+    count = ptr[batch_id + 1] - offset
+    rowptr, col, value = data.adj_t.csr()
+    fn = ops.relabel_one_hop_within_batch if in_batch_only else ops.relabel_one_hop
+    batch_size = n_id.numel()
+    rowptr, col, value, n_id = fn(rowptr, col, value, n_id, bipartite)
+    adj_t = SparseTensor(rowptr=rowptr, col=col, value=value,
+                         sparse_sizes=(rowptr.numel() - 1, n_id.numel()), is_sorted=True)
+    out = data.__class__(adj_t=adj_t)
+    for k, v in data:
+        if isinstance(v, Tensor) and v.dim() > 0 and v.size(0) == data.num_nodes:
+            out[k] = v.index_select(0, n_id)
+    return SubData(out, batch_size, n_id, offset, count)
+
+
 class SubgraphLoader(DataLoader):
     r"""A simple subgraph loader that, given a pre-partioned :obj:`data` object,
     generates subgraphs from mini-batches in :obj:`ptr` (including their 1-hop

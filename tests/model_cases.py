@@ -1,0 +1,157 @@
+"""Shared model-level checks, run on the CPU (kernels swapped for the oracle: host
+orchestration only) and on the GPU (real HIP kernels) by test_models_cpu.py /
+test_gpu_models.py."""
+import numpy as np
+import torch
+
+from oracle import model_oracle as mo
+
+TOL = dict(rtol=2e-4, atol=2e-4)   # fp32 chains of L layers against the fp32 numpy restatement
+
+
+def make_graph(n=1400, parts=6, f_in=24, n_cls=5, seed=0):
+    import torch_geometric_autoscale as tga
+    adj, ptr = tga.synthetic_graph(n, n * 10, parts, cross_fraction=0.3, seed=seed)
+    adj = tga.gcn_norm(adj.set_diag())
+    g = torch.Generator().manual_seed(seed + 1)
+    data = tga.Data(adj_t=adj, num_nodes=n, x=torch.randn(n, f_in, generator=g),
+                    y=torch.randint(0, n_cls, (n,), generator=g))
+    return data, ptr
+
+
+MODEL_CASES = {
+    "gcn": dict(kind="gcn", cfg=dict(num_layers=3, hidden_channels=32, batch_norm=True)),
+    "gcn_linear": dict(kind="gcn", cfg=dict(num_layers=2, hidden_channels=32, linear=True,
+                                            residual=True)),
+    "sage": dict(kind="sage", cfg=dict(num_layers=3, hidden_channels=32)),
+    "gcn2_shared": dict(kind="gcn2", cfg=dict(num_layers=4, hidden_channels=32, alpha=0.1,
+                                              theta=0.5, shared_weights=True, batch_norm=True)),
+    "gcn2": dict(kind="gcn2", cfg=dict(num_layers=3, hidden_channels=32, alpha=0.1, theta=0.5,
+                                       shared_weights=False, residual=True)),
+    "appnp": dict(kind="appnp", cfg=dict(num_layers=4, hidden_channels=32, alpha=0.1)),
+}
+
+
+def make_model(name, data, f_in, n_cls, emb_device, pool_size=None, buffer_size=None):
+    from torch_geometric_autoscale import models
+    case = MODEL_CASES[name]
+    cls = dict(gcn=models.GCN, sage=models.GraphSAGE, gcn2=models.GCN2, appnp=models.APPNP)[case["kind"]]
+    torch.manual_seed(7)
+    model = cls(num_nodes=data.num_nodes, in_channels=f_in, out_channels=n_cls,
+                pool_size=pool_size, buffer_size=buffer_size, device=emb_device, **case["cfg"])
+    # non-trivial batch-norm statistics so that eval-mode bn is not the identity
+    for bn in getattr(model, "bns", []):
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.1)
+    return model
+
+
+def numpy_state(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()
+            if not k.startswith(("reg_modules", "nonreg_modules"))}
+
+
+def check_refresh_sweep(name, model, data, ptr, batch_parts=2):
+    """After mini_inference_vr the tables hold the exact full-graph layer inputs and their
+    aggregates, and the returned matrix is the full-batch output."""
+    import torch_geometric_autoscale as tga
+    case = MODEL_CASES[name]
+    model.eval()
+    loader = tga.EvalSubgraphLoader(data, ptr, batch_size=batch_parts, log=False)
+    out = model.mini_inference_vr(loader=loader)
+    if out.is_cuda:
+        torch.cuda.synchronize()
+    rowptr, col, val = (t.numpy() for t in data.adj_t.csr())
+    inputs, aggs, want = mo.full_graph(case["kind"], numpy_state(model), case["cfg"], rowptr, col,
+                                       val, data.x.numpy())
+    width = model.histories[0].embedding_dim
+    for i in range(model.num_layers):
+        np.testing.assert_allclose(model.histories[i].emb.cpu().numpy(),
+                                   mo.padded(inputs[i], width), **TOL,
+                                   err_msg=f"{name}: M_in of layer {i}")
+        np.testing.assert_allclose(model.histories_ag[i].emb.cpu().numpy(),
+                                   mo.padded(aggs[i], width), **TOL,
+                                   err_msg=f"{name}: M_ag of layer {i}")
+    np.testing.assert_allclose(out.cpu().numpy(), want, **TOL, err_msg=f"{name}: output")
+    return loader, want
+
+
+def check_plain_sweep(name, model, data, ptr):
+    """mini_inference (no aggregate tables) returns the same output and leaves
+    histories[1:] identical to what the VR sweep wrote."""
+    import torch_geometric_autoscale as tga
+    model.eval()
+    loader = tga.EvalSubgraphLoader(data, ptr, batch_size=1, log=False)
+    before = [h.emb.clone() for h in model.histories]
+    for h in model.histories[1:]:
+        h.emb.zero_()
+    out = model(loader=loader)
+    for i in range(1, model.num_layers):
+        np.testing.assert_allclose(model.histories[i].emb.cpu().numpy(),
+                                   before[i].cpu().numpy(), **TOL)
+    return out
+
+
+def check_push_pull_forward(name, model, data, ptr, want, device):
+    """With fresh tables the push/pull forward of a batch reproduces the full-batch rows."""
+    from torch_geometric_autoscale.loader import partition_batch
+    model.eval()
+    for parts in ([1], [0, 3]):
+        sub = partition_batch(data, ptr, parts)
+        b = sub.batch_size
+        ret = model(sub.data.x.to(device), sub.data.adj_t.to(device), b, sub.n_id, sub.offset,
+                    sub.count)
+        out = ret["out"]
+        assert out.size(0) == b
+        np.testing.assert_allclose(out.detach().cpu().numpy(), want[sub.n_id[:b].numpy()], **TOL,
+                                   err_msg=f"{name}: push/pull forward, parts {parts}")
+
+
+def check_incagg_forward(name, model, data, ptr, device):
+    """Incremental-aggregation forward against the explicit formula with the table contents,
+    after the weights moved away from the ones the tables were computed with."""
+    from torch_geometric_autoscale.loader import partition_batch
+    case = MODEL_CASES[name]
+    model.eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(3)).to(p.device))
+    sd = numpy_state(model)
+    t_in = [h.emb.cpu().numpy() for h in model.histories]
+    t_ag = [h.emb.cpu().numpy() for h in model.histories_ag]
+    for parts in ([2], [4, 1]):
+        sub = partition_batch(data, ptr, parts, in_batch_only=True)
+        b = sub.batch_size
+        rp, c, v = (t.numpy() for t in sub.data.adj_t.csr())
+        want = mo.vr_forward(case["kind"], sd, case["cfg"], rp, c, v, sub.data.x.numpy(), t_in, t_ag,
+                             sub.n_id.numpy())
+        for fused in (True, False):
+            model.fused_incagg = fused
+            ret = model.VR_call(sub.data.x.to(device), sub.data.adj_t.to(device), b, sub.n_id,
+                                sub.offset, sub.count)
+            np.testing.assert_allclose(ret["out"].detach().cpu().numpy(), want, **TOL,
+                                       err_msg=f"{name}: VR forward fused={fused} parts {parts}")
+        model.fused_incagg = True
+
+
+def check_training_step(name, model, data, ptr, device, vr):
+    """One optimisation step runs end to end and moves the weights; gradients are finite."""
+    from torch_geometric_autoscale.loader import partition_batch
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    sub = partition_batch(data, ptr, [0, 1], in_batch_only=vr)
+    b = sub.batch_size
+    call = model.VR_call if vr else model
+    out = call(sub.data.x.to(device), sub.data.adj_t.to(device), b, sub.n_id, sub.offset,
+               sub.count)["out"]
+    loss = torch.nn.functional.cross_entropy(out, sub.data.y[:b].to(device))
+    opt.zero_grad()
+    loss.backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(g).all() for g in grads)
+    assert any(float(g.abs().sum()) > 0 for g in grads)
+    opt.step()
+    return float(loss)

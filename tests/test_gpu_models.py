@@ -1,0 +1,107 @@
+"""GPU parity at model level: the four model families through the HIP path (History tables
+in HBM, and in pinned host memory behind the staging pools) against the numpy full-graph
+restatement.  Tolerance 2e-4 (fp32 chains of up to 4 layers; the task's bar is 1e-4 per
+embedding, met by the per-kernel tests)."""
+import numpy as np
+import pytest
+import torch
+
+import model_cases as mc
+from oracle import cpu_path as cp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("name", list(mc.MODEL_CASES))
+def test_model_paths_tables_in_hbm(name, dev):
+    from torch_geometric_autoscale import _lib
+    data, ptr = mc.make_graph()
+    model = mc.make_model(name, data, data.x.size(1), 5, emb_device=dev).to(dev)
+    assert model.pool is None
+    loader, want = mc.check_refresh_sweep(name, model, data, ptr)
+    mc.check_push_pull_forward(name, model, data, ptr, want, dev)
+    mc.check_plain_sweep(name, model, data, ptr)
+    mc.check_incagg_forward(name, model, data, ptr, dev)
+    mc.check_training_step(name, model, data, ptr, dev, vr=False)
+    mc.check_training_step(name, model, data, ptr, dev, vr=True)
+    _lib.check_device_errors()
+
+
+@pytest.mark.parametrize("name", ["gcn2", "sage", "appnp", "gcn"])
+@pytest.mark.parametrize("pool_size", [1, 3])
+def test_model_paths_tables_on_host_with_staging_pools(name, pool_size, dev):
+    from torch_geometric_autoscale import _lib
+    import torch_geometric_autoscale as tga
+    data, ptr = mc.make_graph()
+    loader = tga.EvalSubgraphLoader(data, ptr, batch_size=2, log=False)
+    buffer_size = max(s.n_id.numel() for s in loader) * 2          # main.py:177
+    model = mc.make_model(name, data, data.x.size(1), 5, emb_device=None, pool_size=pool_size,
+                          buffer_size=buffer_size).to(dev)
+    assert model.pool is not None and model.pool_ag is not None
+    assert model.histories[0].emb.is_pinned() and not model.histories[0].emb.is_cuda
+    _, want = mc.check_refresh_sweep(name, model, data, ptr)
+    mc.check_push_pull_forward(name, model, data, ptr, want, dev)
+    mc.check_incagg_forward(name, model, data, ptr, dev)
+    mc.check_training_step(name, model, data, ptr, dev, vr=False)
+    mc.check_training_step(name, model, data, ptr, dev, vr=True)
+    assert len(model.pool._pull_queue) == 0 and len(model.pool_ag._pull_queue) == 0
+    _lib.check_device_errors()
+
+
+def test_staged_pull_mode_matches_zero_copy(dev):
+    """The worker-thread path (host gather into the pinned bounce buffer, then a copy) and the
+    zero-copy gather kernel deliver identical rows."""
+    import torch_geometric_autoscale as tga
+    data, ptr = mc.make_graph()
+    loader = tga.EvalSubgraphLoader(data, ptr, batch_size=2, log=False)
+    buffer_size = max(s.n_id.numel() for s in loader) * 2
+    outs = []
+    for zero_copy in (True, False):
+        model = mc.make_model("gcn2", data, data.x.size(1), 5, emb_device=None, pool_size=2,
+                              buffer_size=buffer_size).to(dev)
+        model.pool.zero_copy = model.pool_ag.zero_copy = zero_copy
+        _, want = mc.check_refresh_sweep("gcn2", model, data, ptr)
+        outs.append([h.emb.clone() for h in model.histories])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_aggregation_gradients(reduce, dev):
+    """dX of spmm and of the incremental aggregate against the oracle's A^T dY."""
+    import torch_geometric_autoscale as tga
+    from helpers import random_csr
+    rng = np.random.default_rng(5)
+    b, m, w = 300, 800, 64
+    rowptr, col, val = random_csr(rng, b, m, 14, hubs={2: 700}, empty_rows=(5,),
+                                  weighted=(reduce == "sum"))
+    adj = tga.SparseTensor(rowptr=torch.from_numpy(rowptr), col=torch.from_numpy(col),
+                           value=None if val is None else torch.from_numpy(val),
+                           sparse_sizes=(b, m), is_sorted=True).to(dev)
+    x = torch.randn(m, w, device=dev, requires_grad=True)
+    add = torch.randn(b, w, device=dev, requires_grad=True)
+    dy = torch.randn(b, w, device=dev)
+    y = tga.spmm(adj, x, reduce, scale=0.7, add=add, add_scale=0.3)
+    y.backward(dy)
+    want = 0.7 * cp.spmm_t(rowptr, col, val, dy.cpu().numpy(), m, reduce)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(add.grad.cpu().numpy(), 0.3 * dy.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+    rowptr, col, val = random_csr(rng, b, b, 14, weighted=(reduce == "sum"))
+    adj = tga.SparseTensor(rowptr=torch.from_numpy(rowptr), col=torch.from_numpy(col),
+                           value=None if val is None else torch.from_numpy(val),
+                           sparse_sizes=(b, b), is_sorted=True).to(dev)
+    x = torch.randn(b, w, device=dev, requires_grad=True)
+    m_in, m_ag = torch.randn(b, w, device=dev), torch.randn(b, w, device=dev)
+    for fused in (True, False):
+        x.grad = None
+        h = tga.incagg_aggregate(adj, x, m_in, m_ag, reduce, fused=fused)
+        h.backward(dy)
+        want = cp.spmm_t(rowptr, col, val, dy.cpu().numpy(), b, reduce)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,146 @@
+"""Host-side pieces that need no GPU: the CSR container, the transposed CSR built for the
+backward pass, loaders / batch tuples, the partition stand-in, and the staging pool's queue
+discipline against the pure-Python model of pool.py:64-123."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_csr
+from oracle import cpu_path as cp
+from oracle.pool_model import PoolModel
+
+
+def test_sparse_tensor_surface():
+    import torch_geometric_autoscale as tga
+    row = torch.tensor([2, 0, 1, 0])
+    col = torch.tensor([1, 2, 0, 0])
+    val = torch.tensor([4.0, 2.0, 3.0, 1.0])
+    a = tga.SparseTensor(row=row, col=col, value=val, sparse_sizes=(3, 3))
+    rowptr, c, v = a.csr()
+    assert rowptr.tolist() == [0, 2, 3, 4] and c.tolist() == [0, 2, 0, 1] and v.tolist() == [1, 2, 3, 4]
+    assert a.storage.row().tolist() == [0, 0, 1, 2] and a.storage.rowcount().tolist() == [2, 1, 1]
+    assert a.size(0) == 3 and a.sparse_sizes() == (3, 3) and a.nnz() == 4
+    assert a.set_value(None).storage.value() is None and a.storage.value() is not None
+    d = a.set_diag()
+    assert d.nnz() == 6 and d.csr()[1].tolist() == [0, 2, 0, 1, 1, 2]
+    p = a.permute(torch.tensor([2, 0, 1]))            # out[i, j] = a[perm[i], perm[j]]
+    dense = torch.zeros(3, 3); dense[a.storage.row(), a.storage.col()] = a.storage.value()
+    pd = torch.zeros(3, 3); pd[p.storage.row(), p.storage.col()] = p.storage.value()
+    assert torch.equal(pd, dense[[2, 0, 1]][:, [2, 0, 1]])
+    s = tga.SparseTensor(row=torch.tensor([0]), col=torch.tensor([1]), sparse_sizes=(2, 2)).to_symmetric()
+    assert s.nnz() == 2
+    m = a.masked_select_nnz(torch.tensor([True, False, True, True]))
+    assert m.nnz() == 3 and m.sparse_sizes() == (3, 3)
+    assert a.max_row_nnz() == 2
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_csr_transpose_matches_oracle(reduce):
+    from torch_geometric_autoscale import ops
+    rng = np.random.default_rng(2)
+    rowptr, col, val = random_csr(rng, 70, 90, 6, hubs={1: 80}, empty_rows=(0,))
+    t_rowptr, t_col, t_val = ops.csr_transpose(torch.from_numpy(rowptr), torch.from_numpy(col),
+                                               torch.from_numpy(val), 70, 90, reduce)
+    assert t_rowptr.dtype == t_col.dtype == torch.int32
+    dy = rng.standard_normal((70, 3))
+    got = cp.spmm_f64(t_rowptr.numpy().astype(np.int64), t_col.numpy().astype(np.int64),
+                      t_val.numpy(), dy.astype(np.float32))
+    want = cp.spmm_t(rowptr, col, val, dy.astype(np.float32), 90, reduce)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5)
+    for r in range(90):                                # source rows ascending in every row
+        seg = t_col[t_rowptr[r]:t_rowptr[r + 1]].tolist()
+        assert seg == sorted(seg)
+    with pytest.raises(RuntimeError):
+        ops.csr_transpose(torch.tensor([0, 1]), torch.tensor([5]), None, 1, 3, "sum")
+
+
+def test_loaders_and_batch_tuples():
+    import torch_geometric_autoscale as tga
+    data, f_in, n_cls = tga.get_data(None, "arxiv", num_parts=6, scale=0.01, seed=3)
+    data.adj_t = tga.gcn_norm(data.adj_t.set_diag())
+    ptr = data.ptr
+    ev = tga.EvalSubgraphLoader(data, ptr, batch_size=2, log=False)
+    seen = []
+    for sub in ev:
+        data_b, b, n_id, offset, count = sub
+        assert data_b.adj_t.sparse_sizes() == (b, n_id.numel())
+        assert int(count.sum()) == b and torch.equal(n_id[:b], torch.arange(int(offset[0]), int(offset[0]) + b))
+        assert torch.equal(data_b.x, data.x[n_id]) and torch.equal(data_b.y, data.y[n_id])
+        assert len(set(n_id.tolist())) == n_id.numel()
+        seen.append(n_id[:b])
+    assert torch.equal(torch.cat(seen), torch.arange(data.num_nodes))
+    tr = tga.SubgraphLoader(data, ptr, batch_size=3, shuffle=True, type='train', IB=True)
+    for data_b, b, n_id, offset, count in tr:
+        assert data_b.adj_t.sparse_sizes() == (b, b) and n_id.numel() == b and offset.numel() == 3
+    ns_loader = tga.SubgraphLoader(data, ptr, batch_size=2, shuffle=False, type='train', IB=False,
+                                   num_neighbors=3)
+    for data_b, b, n_id, offset, count in ns_loader:
+        assert int(data_b.adj_t.storage.rowcount().max()) <= 3
+
+
+def test_partition_stand_in_and_permute():
+    import torch_geometric_autoscale as tga
+    adj, _ = tga.synthetic_graph(500, 4000, 5, seed=1)
+    perm, ptr = tga.metis(adj, 4, log=False)
+    assert sorted(perm.tolist()) == list(range(500)) and ptr[0] == 0 and ptr[-1] == 500
+    assert ptr.numel() == 5 and int((ptr[1:] - ptr[:-1]).min()) > 0
+    data = tga.Data(adj_t=adj, x=torch.arange(500.0).view(-1, 1), num_nodes=500)
+    out = tga.permute(data, perm, log=False)
+    assert torch.equal(out.x.view(-1), perm.to(torch.float32))
+    r, c, _ = out.adj_t.coo()
+    orig = set(zip(*[t.tolist() for t in adj.coo()[:2]]))
+    assert all((int(perm[i]), int(perm[j])) in orig for i, j in zip(r[:200].tolist(), c[:200].tolist()))
+    cl = torch.tensor([1, 0, 1, 0])
+    perm2, ptr2 = tga.metis(tga.SparseTensor(rowptr=torch.tensor([0, 0, 0, 0, 0]), col=torch.zeros(0, dtype=torch.long),
+                                             sparse_sizes=(4, 4)), 2, cluster=cl)
+    assert perm2.tolist() == [1, 3, 0, 2] and ptr2.tolist() == [0, 2, 4]
+
+
+def test_pool_queue_matches_reference_model(monkeypatch):
+    """Same launches, same slots, same order as the model of pool.py -- with the copies and
+    streams replaced by a recording backend (no GPU involved)."""
+    from torch_geometric_autoscale import pool as pool_mod
+    log = []
+
+    class FakeStream:
+        def wait_stream(self, other): pass
+        def synchronize(self): pass
+
+    p = pool_mod.AsyncIOPool(pool_size=2, buffer_size=8, embedding_dim=4)
+    monkeypatch.setattr(p, "_pull_stream", lambda idx: FakeStream())
+    monkeypatch.setattr(p, "_async_pull", lambda idx, src, o, c, index: log.append(("launch_pull", idx, src)))
+    monkeypatch.setattr(p, "synchronize_pull", lambda: log.append(("sync_pull", p._pull_queue[0][0], p._pull_queue[0][1])) or p._pull_queue[0][0])
+    m = PoolModel(2)
+    script = ["pull a", "pull b", "pull c", "sync", "free", "pull d", "sync", "free", "sync", "free",
+              "pull e", "sync", "free", "sync", "free"]
+    for cmd in script:
+        if cmd.startswith("pull"):
+            tag = cmd.split()[1]
+            p.async_pull(tag, None, None, torch.zeros(0, dtype=torch.long)); m.async_pull(tag)
+        elif cmd == "sync":
+            assert p.synchronize_pull() == m.synchronize_pull()
+        else:
+            p.free_pull(); m.free_pull()
+        assert [q[0] for q in p._pull_queue] == [q[0] for q in m.queue]
+        assert p._pull_index == m.pull_index
+    assert log == m.log
+
+
+def test_history_interface_on_host():
+    import torch_geometric_autoscale as tga
+    h = tga.History(10, 3)
+    assert h.emb.shape == (10, 3) and float(h.emb.abs().sum()) == 0 and not h.emb.is_cuda
+    assert list(h.state_dict().keys()) == []                 # emb is not a buffer
+    h.to(torch.float64)                                      # must not move / convert emb
+    assert h.emb.dtype == torch.float32
+    x = torch.arange(12.0).view(4, 3)
+    h.push(x, torch.tensor([7, 1, 3, 9]))
+    assert torch.equal(h.pull(torch.tensor([1, 9])), x[[1, 3]])
+    h.push(x, torch.arange(4), torch.tensor([5, 0]), torch.tensor([3, 1]))
+    assert torch.equal(h.emb[5:8], x[:3]) and torch.equal(h.emb[0], x[3])
+    with pytest.raises(ValueError):
+        h.push(x)
+    h.push(torch.ones(10, 3))
+    assert float(h.pull().sum()) == 30
+    with pytest.raises(NotImplementedError):
+        h(x)

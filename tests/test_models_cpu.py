@@ -1,0 +1,23 @@
+"""Host orchestration of the four models (sweeps, push/pull forward, incremental forward,
+one training step) with the HIP entry points swapped for the CPU oracle -- what runs here
+is the Python control flow, the History bookkeeping and the batch construction; the
+kernels themselves are covered by the `-m gpu` tests."""
+import pytest
+import torch
+
+import model_cases as mc
+from cpu_shim import cpu_kernels
+
+
+@pytest.mark.parametrize("name", list(mc.MODEL_CASES))
+def test_model_paths_on_cpu(name):
+    data, ptr = mc.make_graph()
+    f_in, n_cls = data.x.size(1), 5
+    with cpu_kernels():
+        model = mc.make_model(name, data, f_in, n_cls, emb_device="cpu")
+        loader, want = mc.check_refresh_sweep(name, model, data, ptr)
+        mc.check_push_pull_forward(name, model, data, ptr, want, torch.device("cpu"))
+        mc.check_plain_sweep(name, model, data, ptr)
+        mc.check_incagg_forward(name, model, data, ptr, torch.device("cpu"))
+        mc.check_training_step(name, model, data, ptr, torch.device("cpu"), vr=False)
+        mc.check_training_step(name, model, data, ptr, torch.device("cpu"), vr=True)
