@@ -372,7 +372,8 @@ static int check_common(const int32_t *rowptr, const int32_t *col, const float *
   INCAGG_REQUIRE(ldy >= width, "ldy %lld < width %lld", (long long)ldy, (long long)width);
   INCAGG_REQUIRE(!x || ldx >= width, "ldx %lld < width %lld", (long long)ldx, (long long)width);
   INCAGG_REQUIRE(!add || ldadd >= width, "ldadd %lld < width %lld", (long long)ldadd, (long long)width);
-  INCAGG_REQUIRE(n_cols == 0 || (x && col), "null x or col with n_cols > 0");
+  // col may be NULL only for an adjacency without edges (nnz is known on the device only)
+  INCAGG_REQUIRE(n_cols == 0 || x, "null x with n_cols > 0");
   INCAGG_REQUIRE((const void *)x != (const void *)y, "y must not alias x");
   return INCAGG_OK;
 }
