@@ -98,7 +98,7 @@ def cpu_baseline(batches, layers, width, seconds):
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     cp.set_threads(cores)
     rng = np.random.default_rng(1)
-    edges, t_total, used = 0, 0.0, 0
+    edges, t_total, used, prepared = 0, 0.0, 0, []
     for rowptr, col, val, m in batches:
         b = rowptr.size - 1
         x = rng.standard_normal((m, width)).astype(np.float32)
@@ -109,7 +109,10 @@ def cpu_baseline(batches, layers, width, seconds):
         t_val = val[order]
         t_rowptr = np.zeros(m + 1, dtype=np.int64)
         np.cumsum(np.bincount(col, minlength=m), out=t_rowptr[1:])
-        cp.spmm(rowptr, col, val, x)  # warm
+        prepared.append((rowptr, col, val, x, t_rowptr, t_col, t_val, dy))
+    cp.spmm(*prepared[0][:4])  # warm
+    while t_total < seconds:
+        rowptr, col, val, x, t_rowptr, t_col, t_val, dy = prepared[used % len(prepared)]
         t0 = time.perf_counter()
         for _ in range(layers):
             cp.spmm(rowptr, col, val, x)
@@ -117,10 +120,8 @@ def cpu_baseline(batches, layers, width, seconds):
         t_total += time.perf_counter() - t0
         edges += 2 * layers * col.size
         used += 1
-        if t_total >= seconds:
-            break
     return {"value": edges / t_total, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"forward + transposed fp32 CSR aggregation of {used} partition batch(es) x "
+            "sample": f"forward + transposed fp32 CSR aggregation of {used} partition-batch steps x "
                       f"{layers} layers at width {width} (dense updates, push/pull and optimizer "
                       f"not included), C/OpenMP oracle, {t_total:.1f} s"}
 

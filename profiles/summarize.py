@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condenses a `rocprofv3 --kernel-trace --stats --output-format csv` directory into a short
+per-kernel table for the timed steps of bench.py (the last `steps` x 16 aggregation launches
+mark the timed region).  Usage: summarize.py <rocprof_dir> <steps> > summary.txt"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(n):
+    n = re.sub(r'^void ', '', n)
+    m = re.match(r'([\w:]+)', n)
+    s = m.group(1) if m else n[:40]
+    if s.startswith('Cijk'):
+        s = 'hipBLASLt_GEMM_' + n[5:14] + '_MT' + re.search(r'MT(\w+?)_', n).group(1)
+    if 'elementwise' in n:
+        mm = re.search(r'(\w+Functor\w*|\w+_kernel_impl|launch_\w+)', n[n.find('<'):])
+        s += ':' + (mm.group(1) if mm else '')
+    return s[:78]
+
+
+def main():
+    d, steps = sys.argv[1], int(sys.argv[2])
+    per_step_aggs = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    idx = [i for i, r in enumerate(rows) if 'spmm_rows_kernel' in r['Kernel_Name']]
+    seg = rows[idx[-steps * per_step_aggs]:]
+    t0 = int(seg[0]['Start_Timestamp'])
+    t1 = max(int(r['End_Timestamp']) for r in seg)
+    busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg)
+    print(f"# timed region: {steps} steps, span {(t1 - t0) / 1e6:.2f} ms, GPU busy {busy / 1e6:.2f} ms, "
+          f"{len(seg) / steps:.0f} kernels/step")
+    agg = collections.defaultdict(lambda: [0, 0, None])
+    for r in seg:
+        k = short(r['Kernel_Name'])
+        dur = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        agg[k][0] += 1
+        agg[k][1] += dur
+        agg[k][2] = (r['VGPR_Count'], r['SGPR_Count'], r['LDS_Block_Size'])
+    print(f"{'kernel':78s} {'n/step':>7s} {'ms/step':>8s} {'avg_us':>8s}  vgpr/sgpr/lds")
+    for k, (c, dur, res) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+        print(f"{k:78s} {c / steps:7.1f} {dur / steps / 1e6:8.3f} {dur / c / 1e3:8.1f}  {'/'.join(res)}")
+
+
+if __name__ == '__main__':
+    main()
