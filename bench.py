@@ -8,7 +8,9 @@ batch's [B, M] one-hop adjacency, push of the B fresh rows into the next layer's
 table, pull of the M - B out-of-batch rows), the dense GCNII updates, the loss, the
 backward pass (8 transposed aggregations) and the Adam step.  Inputs (graph, features,
 History tables) are resident in HBM before the timed region.  `value` counts every edge
-of every aggregation, forward and backward: 2 * L * nnz(adj_t) per step.
+that an aggregation launch processes: L * nnz(adj_t) forward; backward nnz(adj_t) for
+layer 0 plus, for the other layers, the edges whose source row is in the batch (the
+pulled out-of-batch rows are constants, no gradient is aggregated for them).
 
 Prints ONE JSON line (rank 0).  Data is synthetic: a seeded power-law graph with the
 public ogbn-products statistics planted in 150 communities (no dataset download).
@@ -168,12 +170,20 @@ def main():
     for p in my_parts[:need]:
         sub = partition_batch(loader_data, ptr, [p], in_batch_only=(args.mode == "vr"))
         adj = sub.data.adj_t.to(dev)
-        adj.device_csr_t("sum")                    # backward CSR, once per batch
+        t_rowptr = adj.device_csr_t("sum")[0]       # backward CSR, once per batch
         nid_dev = sub.n_id.to(dev)
+        e_all, e_ib = adj.nnz(), int(t_rowptr[sub.batch_size])
+        # edges aggregated per step: L forward aggregations over all E edges; backward:
+        # layer 0 over all E (its input is computed from features for every row), layers
+        # >= 1 only over edges whose source row is in the batch (pulled rows are constants)
+        if args.mode == "vr":
+            step_edges = 2 * args.layers * e_all
+        else:
+            step_edges = args.layers * e_all + e_all + (args.layers - 1) * e_ib
         batches.append({
             "adj": adj, "host": sub.data.adj_t, "b": sub.batch_size, "n_id": sub.n_id,
             "nid_dev": nid_dev, "offset": sub.offset, "count": sub.count,
-            "x": x_all[nid_dev], "y": y_all[nid_dev[:sub.batch_size]],
+            "x": x_all[nid_dev], "y": y_all[nid_dev[:sub.batch_size]], "edges": step_edges,
         })
 
     model = GCN2(n, f_in, args.hidden, n_cls, args.layers, alpha=0.1, theta=0.5,
@@ -203,7 +213,7 @@ def main():
         loss = crit(out, bt["y"])
         loss.backward()
         opt.step()
-        return 2 * args.layers * bt["adj"].nnz()
+        return bt["edges"]
 
     for i in range(args.warmup):
         step(i)

@@ -12,7 +12,9 @@
 // destination row; flops are 2*E*width, i.e. ~0.5 flop per gathered byte.
 #include "common.h"
 
+#include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -23,8 +25,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
-constexpr int kHubThreshold = 512;  // rows with more edges are sliced
-constexpr int kHubSlice = 256;      // edges per slice
+// Rows with more than hub_threshold edges are cut into hub_slice-edge slices.  Compile-time
+// defaults; INCAGG_HUB_THRESHOLD / INCAGG_HUB_SLICE override them for tuning runs.
+constexpr int kHubThreshold = 512;
+constexpr int kHubSlice = 256;
 constexpr int kQueueCap = 1 << 20;  // slices per call that the queue can hold
 
 template <int VEC> struct VT;
@@ -46,6 +50,9 @@ struct SpmmArgs {
   const float *val;
   const float *x;
   long long ldx;
+  const float *x2;  // source rows [split, n_cols) live here (row c at x2 + (c - split) * ldx2)
+  long long ldx2;
+  int split;
   const float *m_in;
   long long ldin;
   const float *m_ag;
@@ -61,6 +68,7 @@ struct SpmmArgs {
   float scale;
   float add_scale;
   int hub_threshold;
+  int hub_slice;
   int2 *queue;
   int *q_count;
   int *q_count_next;
@@ -87,7 +95,7 @@ __device__ __forceinline__ void edge_step(const SpmmArgs &a, int my_c, float my_
   for (int u = 0; u < U; u++) {
     const int c = __builtin_amdgcn_readlane(my_c, j + u);
     w[u] = readlane_f(my_v, j + u);
-    const float *xr = a.x + (size_t)c * a.ldx;
+    const float *xr = c < a.split ? a.x + (size_t)c * a.ldx : a.x2 + (size_t)(c - a.split) * a.ldx2;
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) xv[u][ch] = ldv<VEC>(xr + off[ch]);
     if (INCAGG) {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
   for (int ch = 0; ch < CH; ch++) acc[ch] = V(0.f);
 
   if (deg > a.hub_threshold) {
-    const int ns = (deg + kHubSlice - 1) / kHubSlice;
+    const int ns = (deg + a.hub_slice - 1) / a.hub_slice;
     int base = 0;
     if (lane == 0) base = atomicAdd(a.q_count, ns);
     base = rfl(base);
@@ -229,8 +237,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_hub_kernel(const S
     const int k = rfl(ent.y);
     const int rs0 = rfl(a.rowptr[row]);
     const int re0 = rfl(a.rowptr[row + 1]);
-    const int rs = rs0 + k * kHubSlice;
-    const int re = min(re0, rs + kHubSlice);
+    const int rs = rs0 + k * a.hub_slice;
+    const int re = min(re0, rs + a.hub_slice);
     V acc[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) acc[ch] = V(0.f);
@@ -307,14 +315,23 @@ static int hub_queue_for(hipStream_t stream, HubQueue **out) {
   return INCAGG_OK;
 }
 
+static int env_int(const char *name, int fallback) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : fallback;
+}
+
 template <int VEC, int CH, bool INCAGG>
 static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
-  const bool may_have_hubs = max_row_nnz < 0 || max_row_nnz > kHubThreshold;
+  static const int hub_threshold = std::max(1, env_int("INCAGG_HUB_THRESHOLD", kHubThreshold));
+  static const int hub_slice = std::max(1, env_int("INCAGG_HUB_SLICE", kHubSlice));
+  static const int hub_blocks = std::max(1, env_int("INCAGG_HUB_BLOCKS", 2048));
+  a.hub_slice = hub_slice;
+  const bool may_have_hubs = max_row_nnz < 0 || max_row_nnz > hub_threshold;
   HubQueue *q = nullptr;
   if (may_have_hubs) {
     int rc = hub_queue_for(stream, &q);
     if (rc) return rc;
-    a.hub_threshold = kHubThreshold;
+    a.hub_threshold = hub_threshold;
     a.queue = q->entries;
     a.q_count = q->counters + q->parity;
     a.q_count_next = q->counters + (q->parity ^ 1);
@@ -330,7 +347,7 @@ static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
                      0, stream, a);
   INCAGG_HIP_TRY(hipGetLastError());
   if (may_have_hubs) {
-    hipLaunchKernelGGL((spmm_hub_kernel<VEC, CH, INCAGG>), dim3(2048),
+    hipLaunchKernelGGL((spmm_hub_kernel<VEC, CH, INCAGG>), dim3(hub_blocks),
                        dim3(kWave * kWavesPerBlock), 0, stream, a);
     INCAGG_HIP_TRY(hipGetLastError());
     q->parity ^= 1;
@@ -379,21 +396,30 @@ static int check_common(const int32_t *rowptr, const int32_t *col, const float *
 }
 
 extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
-                                   const float *x, int64_t ldx, int64_t n_rows, int64_t n_cols,
-                                   int64_t width, int reduce, float scale, const float *add,
-                                   int64_t ldadd, float add_scale, int64_t max_row_nnz, float *y,
-                                   int64_t ldy, void *stream) {
+                                   const float *x, int64_t ldx, const float *x_halo,
+                                   int64_t ld_halo, int64_t n_split, int64_t n_rows,
+                                   int64_t n_cols, int64_t width, int reduce, float scale,
+                                   const float *add, int64_t ldadd, float add_scale,
+                                   int64_t max_row_nnz, float *y, int64_t ldy, void *stream) {
   int rc = check_common(rowptr, col, x, ldx, n_rows, n_cols, width, reduce, add, ldadd, y, ldy);
   if (rc) return rc;
   if (n_rows == 0 || width == 0) return INCAGG_OK;
+  if (!x_halo) n_split = n_cols;
+  INCAGG_REQUIRE(n_split >= 0 && n_split <= n_cols, "n_split %lld outside [0, %lld]",
+                 (long long)n_split, (long long)n_cols);
+  INCAGG_REQUIRE(!x_halo || ld_halo >= width, "ld_halo %lld < width %lld", (long long)ld_halo,
+                 (long long)width);
+  INCAGG_REQUIRE((const void *)x_halo != (const void *)y, "y must not alias x_halo");
   SpmmArgs a{};
   a.rowptr = rowptr; a.col = col; a.val = val; a.x = x; a.ldx = ldx;
+  a.x2 = x_halo; a.ldx2 = ld_halo; a.split = (int)n_split;
   a.add = add; a.ldadd = ldadd; a.y = y; a.ldy = ldy;
   a.n_rows = (int)n_rows; a.n_cols = (int)n_cols; a.width = (int)width;
   a.mean = reduce == INCAGG_REDUCE_MEAN; a.scale = scale; a.add_scale = add_scale;
   rc = error_flag_address(&a.err);
   if (rc) return rc;
-  const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(add, ldadd) && rows_vec4(y, ldy);
+  const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(x_halo, ld_halo) &&
+                    rows_vec4(add, ldadd) && rows_vec4(y, ldy);
   return dispatch_spmm<false>(a, vec4, max_row_nnz, static_cast<hipStream_t>(stream));
 }
 
@@ -412,6 +438,7 @@ extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *
   INCAGG_REQUIRE((const void *)m_in != (const void *)h, "h must not alias m_in");
   SpmmArgs a{};
   a.rowptr = rowptr; a.col = col; a.val = val; a.x = x; a.ldx = ldx;
+  a.split = (int)n_rows;
   a.m_in = m_in; a.ldin = ldin; a.m_ag = m_ag; a.ldag = ldag;
   a.add = add; a.ldadd = ldadd; a.y = h; a.ldy = ldh;
   a.n_rows = (int)n_rows; a.n_cols = (int)n_rows; a.width = (int)width;

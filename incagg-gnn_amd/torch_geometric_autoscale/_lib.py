@@ -19,8 +19,8 @@ SIGNATURES = {
     "incagg_abi_version": (_int, []),
     "incagg_device_count": (_int, []),
     "incagg_check_device_errors": (_int, []),
-    "incagg_spmm_csr_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _f32, _vp,
-                                   _i64, _f32, _i64, _vp, _i64, _vp]),
+    "incagg_spmm_csr_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64,
+                                   _int, _f32, _vp, _i64, _f32, _i64, _vp, _i64, _vp]),
     "incagg_spmm_csr_incagg_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
                                           _i64, _int, _f32, _vp, _i64, _f32, _i64, _vp, _i64, _vp]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),

@@ -29,24 +29,36 @@ def _as_rows(x: Tensor) -> Tensor:
 
 class _SpMM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, add, adj, reduce, scale, add_scale):
+    def forward(ctx, x, x_halo, add, adj, reduce, scale, add_scale):
         rowptr, col, val = adj.device_csr()
         y = ops.spmm_csr(rowptr, col, val, x, adj.size(1), reduce, scale, add, add_scale,
-                         adj.max_row_nnz())
+                         adj.max_row_nnz(), x_halo=x_halo)
         ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
         ctx.x_rows = x.size(0)
+        ctx.halo_rows = None if x_halo is None else x_halo.size(0)
         ctx.has_add = add is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        dx = dadd = None
+        dx = dhalo = dadd = None
         dy = _as_rows(dy)
-        if ctx.needs_input_grad[0]:
-            dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, ctx.x_rows)
-        if ctx.has_add and ctx.needs_input_grad[1]:
+        n_cols = ctx.adj.size(1)
+        if ctx.halo_rows is None:
+            if ctx.needs_input_grad[0]:
+                dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, 0, n_cols,
+                                           ctx.x_rows)
+        else:
+            # only the rows somebody needs: the pulled History rows are constants
+            if ctx.needs_input_grad[0]:
+                dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, 0, ctx.x_rows,
+                                           ctx.x_rows)
+            if ctx.needs_input_grad[1]:
+                dhalo = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, ctx.x_rows,
+                                              n_cols, ctx.halo_rows)
+        if ctx.has_add and ctx.needs_input_grad[2]:
             dadd = dy * ctx.add_scale
-        return dx, dadd, None, None, None, None
+        return dx, dhalo, dadd, None, None, None, None
 
 
 class _IncAgg(torch.autograd.Function):
@@ -65,32 +77,45 @@ class _IncAgg(torch.autograd.Function):
         dx = dadd = None
         dy = _as_rows(dy)
         if ctx.needs_input_grad[0]:
-            dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, ctx.x_rows)
+            dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, 0, ctx.adj.size(1),
+                                       ctx.x_rows)
         if ctx.has_add and ctx.needs_input_grad[1]:
             dadd = dy * ctx.add_scale
         return dx, dadd, None, None, None, None, None, None
 
 
-def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: float,
-                          x_rows: int) -> Tensor:
+def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: float, lo: int,
+                          hi: int, out_rows: int) -> Tensor:
+    """Rows [lo, hi) of  scale * A^T dY  (A^T has one row per source row of A), padded
+    with zero rows up to ``out_rows``."""
     t_rowptr, t_col, t_val, t_max = adj.device_csr_t(reduce)
-    n_cols = adj.size(1)
-    dx = ops.spmm_csr(t_rowptr, t_col, t_val, dy, adj.size(0), "sum", scale, None, 0.0, t_max)
-    if x_rows > n_cols:  # x had rows the adjacency never references
-        pad = torch.zeros((x_rows - n_cols, dy.size(1)), dtype=dy.dtype, device=dy.device)
+    hi = min(hi, adj.size(1))
+    # a window of row pointers addresses the same col / val arrays: no copy
+    dx = ops.spmm_csr(t_rowptr[lo:hi + 1], t_col, t_val, dy, adj.size(0), "sum", scale, None,
+                      0.0, t_max)
+    if out_rows > hi - lo:  # x had rows the adjacency never references
+        pad = torch.zeros((out_rows - (hi - lo), dy.size(1)), dtype=dy.dtype, device=dy.device)
         dx = torch.cat([dx, pad], dim=0)
     return dx
 
 
 def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
-         add: Optional[Tensor] = None, add_scale: float = 0.0) -> Tensor:
-    """``adj @ x`` / ``spmm(adj, x, reduce)`` with an optional fused ``+ add_scale * add``."""
+         add: Optional[Tensor] = None, add_scale: float = 0.0,
+         x_halo: Optional[Tensor] = None) -> Tensor:
+    """``adj @ x`` / ``spmm(adj, x, reduce)`` with an optional fused ``+ add_scale * add``.
+
+    ``x_halo``: the source rows are ``[x ; x_halo]`` without concatenating them -- ``x``
+    the fresh in-batch rows, ``x_halo`` the pulled out-of-batch History rows.  The
+    backward pass then aggregates only over the columns of ``x`` (and of ``x_halo`` if
+    it requires a gradient, which pulled rows never do)."""
     if reduce not in ("sum", "add", "mean"):
         raise ValueError(f"unsupported reduce '{reduce}'")
     x = _as_rows(x)
     if add is not None:
         add = _as_rows(add)
-    return _SpMM.apply(x, add, adj, "mean" if reduce == "mean" else "sum", float(scale),
+    if x_halo is not None:
+        x_halo = _as_rows(x_halo)
+    return _SpMM.apply(x, x_halo, add, adj, "mean" if reduce == "mean" else "sum", float(scale),
                        float(add_scale))
 
 
@@ -114,7 +139,7 @@ def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,
     # two-pass form: one streaming subtract, then the plain aggregation with M_ag
     # folded in afterwards; gathers touch one operand instead of two.
     d = _RowsSub.apply(x[:b], m_in)
-    h = _SpMM.apply(d, None, adj, red, 1.0, 0.0) + m_ag[:b, :x.size(1)]
+    h = _SpMM.apply(d, None, None, adj, red, 1.0, 0.0) + m_ag[:b, :x.size(1)]
     if scale != 1.0:
         h = h * scale
     if add is not None:

@@ -4,8 +4,9 @@ from typing import Any, Dict, Optional
 
 import torch.nn.functional as F
 from torch import Tensor
-from torch.nn import Linear, ModuleList
+from torch.nn import ModuleList
 
+from ..nn import RowsLinear
 from .base import ScalableGNN
 
 
@@ -23,8 +24,8 @@ class APPNP(ScalableGNN):
         self.dropout = dropout
 
         self.lins = ModuleList()
-        self.lins.append(Linear(in_channels, hidden_channels))
-        self.lins.append(Linear(hidden_channels, out_channels))
+        self.lins.append(RowsLinear(in_channels, hidden_channels))
+        self.lins.append(RowsLinear(hidden_channels, out_channels))
 
         self.reg_modules = self.lins[:1]
         self.nonreg_modules = self.lins[1:]

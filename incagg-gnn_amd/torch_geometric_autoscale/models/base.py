@@ -231,6 +231,34 @@ class ScalableGNN(torch.nn.Module):
         self.pool.free_pull()
         return out, 0.0
 
+    def _push_and_pull_split(self, history, x: Tensor, batch_size: Optional[int],
+                             n_id: Optional[Tensor], offset: Optional[Tensor],
+                             count: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
+        """:meth:`push_and_pull` without the concatenation: returns the fresh in-batch rows
+        and, separately, the pulled out-of-batch rows (``None`` when nothing is pulled).
+        The aggregation kernel reads its source rows from the two pieces, and gradients
+        only ever flow into the first.  With staging pools the second piece is a view into
+        slot memory that stays valid until :meth:`_release_halo`."""
+        if n_id is None or batch_size is None:
+            out, _ = self.push_and_pull(history, x, batch_size, n_id, offset, count)
+            return out, None
+        x = x if x.size(0) == batch_size else x[:batch_size]
+        if not self._async:
+            history.push(x.detach(), n_id[:batch_size], offset, count)
+            halo = history.pull(n_id[batch_size:]) if n_id.numel() > batch_size else None
+            return x, halo
+        halo = self.pool.synchronize_pull()[:n_id.numel() - batch_size]
+        self.pool.async_push(x.detach(), offset, count, history.emb)
+        self._halo_in_slot = True
+        return x, halo
+
+    def _release_halo(self) -> None:
+        """The kernels reading the pulled rows have been launched: hand the staging slot back
+        (its refill is ordered behind them on the device)."""
+        if getattr(self, "_halo_in_slot", False):
+            self.pool.free_pull()
+            self._halo_in_slot = False
+
     def push_only(self, history, x: Tensor, batch_size: Optional[int] = None,
                   n_id: Optional[Tensor] = None, offset: Optional[Tensor] = None,
                   count: Optional[Tensor] = None) -> Tuple[Tensor, float]:
@@ -287,24 +315,32 @@ class ScalableGNN(torch.nn.Module):
         if not use_aggregation:
             x = x[:b]
         adj = self._adj(adj_t)
+        halo = None  # pulled out-of-batch rows of the current layer input (never concatenated)
         for i in range(self.num_layers):
             x = self._layer_input(i, x)
             if not use_aggregation:
                 h = self._update(i, x[:b], x, state)
             else:
+                if halo is not None:
+                    halo = self._layer_input(i, halo)
                 mix = self._mix(i, state, b)
                 xa = self._pre_aggregate(i, x)
                 if mix is not None:
-                    h = self._update_mixed(i, spmm(adj, x, self.agg_reduce, *mix), x, state)
+                    agg = spmm(adj, x, self.agg_reduce, *mix, x_halo=halo)
+                    h = self._update_mixed(i, agg, x, state)
                 elif xa is not None:
-                    h = self._update(i, spmm(adj, xa, reduce=self.agg_reduce), x, state, pre=True)
+                    ha = None if halo is None else self._pre_aggregate(i, halo)
+                    agg = spmm(adj, xa, reduce=self.agg_reduce, x_halo=ha)
+                    h = self._update(i, agg, x, state, pre=True)
                 else:
-                    h = self._update(i, spmm(adj, x, reduce=self.agg_reduce), x, state)
+                    agg = spmm(adj, x, reduce=self.agg_reduce, x_halo=halo)
+                    h = self._update(i, agg, x, state)
+                self._release_halo()
             if i < self.num_layers - 1:
                 nid = None if n_id is None else n_id.to(self.emb_device)
                 if use_aggregation:
-                    x, _ = self.push_and_pull(self.histories[i + 1], h, batch_size, nid, offset,
-                                              count)
+                    x, halo = self._push_and_pull_split(self.histories[i + 1], h, batch_size, nid,
+                                                        offset, count)
                 else:
                     x, _ = self.push_only(self.histories[i + 1], h, batch_size, nid, offset, count)
             else:

@@ -3,9 +3,9 @@ from typing import Any, Dict, Optional
 
 import torch.nn.functional as F
 from torch import Tensor
-from torch.nn import BatchNorm1d, Linear, ModuleList
+from torch.nn import BatchNorm1d, ModuleList
 
-from ..nn import GCNConv
+from ..nn import GCNConv, RowsLinear
 from .base import ScalableGNN
 
 
@@ -26,8 +26,8 @@ class GCN(ScalableGNN):
 
         self.lins = ModuleList()
         if linear:
-            self.lins.append(Linear(in_channels, hidden_channels))
-            self.lins.append(Linear(hidden_channels, out_channels))
+            self.lins.append(RowsLinear(in_channels, hidden_channels))
+            self.lins.append(RowsLinear(hidden_channels, out_channels))
 
         self.convs = ModuleList()
         for i in range(num_layers):
@@ -88,7 +88,7 @@ class GCN(ScalableGNN):
             if self.batch_norm:
                 h = self.bns[layer](h)
             if self.residual and h.size(-1) == x.size(-1):
-                h = h + x[:h.size(0)]
+                h = h + (x if x.size(0) == h.size(0) else x[:h.size(0)])
             h = h.relu_()
         if layer == self.num_layers - 1 and self.linear:
             h = F.dropout(h, p=self.dropout, training=self.training)

@@ -1,12 +1,11 @@
 """GCNII on historical embeddings (constructor and module layout of models/gcn2.py:22-76)."""
 from typing import Any, Dict, Optional
 
-import torch
 import torch.nn.functional as F
 from torch import Tensor
-from torch.nn import BatchNorm1d, Linear, ModuleList
+from torch.nn import BatchNorm1d, ModuleList
 
-from ..nn import GCN2Conv
+from ..nn import GCN2Conv, RowsLinear
 from .base import ScalableGNN
 
 
@@ -26,8 +25,8 @@ class GCN2(ScalableGNN):
         self.residual = residual
 
         self.lins = ModuleList()
-        self.lins.append(Linear(in_channels, hidden_channels))
-        self.lins.append(Linear(hidden_channels, out_channels))
+        self.lins.append(RowsLinear(in_channels, hidden_channels))
+        self.lins.append(RowsLinear(hidden_channels, out_channels))
 
         self.convs = ModuleList([
             GCN2Conv(hidden_channels, alpha=alpha, theta=theta, layer=i + 1,
@@ -64,7 +63,7 @@ class GCN2(ScalableGNN):
         if self.batch_norm:
             h = self.bns[layer](h)
         if self.residual and h.size(-1) == x.size(-1):
-            h = h + x[:h.size(0)]
+            h = h + (x if x.size(0) == h.size(0) else x[:h.size(0)])
         h = h.relu_()
         if layer == self.num_layers - 1:
             h = F.dropout(h, p=self.dropout, training=self.training)
@@ -82,6 +81,4 @@ class GCN2(ScalableGNN):
         return 1.0 - conv.alpha, state['x_0'], conv.alpha
 
     def _update_mixed(self, layer: int, mixed: Tensor, x: Tensor, state: Dict[str, Any]) -> Tensor:
-        conv = self.convs[layer]
-        h = torch.addmm(mixed, mixed, conv.weight1, beta=1.0 - conv.beta, alpha=conv.beta)
-        return self._post(layer, h, x)
+        return self._post(layer, self.convs[layer].update_mixed(mixed), x)

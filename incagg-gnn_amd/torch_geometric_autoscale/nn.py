@@ -19,6 +19,76 @@ from .aggregate import spmm
 from .sparse import SparseTensor
 
 
+def _tn_product(a: Tensor, b: Tensor) -> Tensor:
+    """``a^T @ b`` for tall operands ([rows, m], [rows, n], rows >> m, n): the shape of every
+    weight gradient here.  A [m, n] output gives a GEMM only a handful of tiles while the
+    reduction runs over 10^4..10^5 rows, so the rows are cut into 8 slabs that run as one
+    batched product (8x the tiles) and are summed afterwards."""
+    rows = a.size(0)
+    slabs = 8
+    if rows < 4096 or a.dim() != 2:
+        return a.t() @ b
+    k = (rows // slabs) * slabs
+    out = torch.bmm(a[:k].view(slabs, k // slabs, a.size(1)).transpose(1, 2),
+                    b[:k].view(slabs, k // slabs, b.size(1))).sum(0)
+    if k < rows:
+        out.addmm_(a[k:].t(), b[k:])
+    return out
+
+
+class _RowsLinear(torch.autograd.Function):
+    """``x @ W^T + b`` over node rows with the weight gradient evaluated by :func:`_tn_product`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        if bias is None:
+            return x @ weight.t()
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = _tn_product(dy, x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class _TwoTermUpdate(torch.autograd.Function):
+    """``h @ W1 + x0 @ W2`` (``x0`` / ``W2`` optional) with split-row weight gradients."""
+
+    @staticmethod
+    def forward(ctx, h, w1, x0, w2):
+        ctx.save_for_backward(h, w1, x0, w2)
+        if x0 is None:
+            return h @ w1
+        return torch.addmm(x0 @ w2, h, w1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w1, x0, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dh = dy @ w1.t() if ctx.needs_input_grad[0] else None
+        dw1 = _tn_product(h, dy) if ctx.needs_input_grad[1] else None
+        dx0 = dw2 = None
+        if x0 is not None:
+            dx0 = dy @ w2.t() if ctx.needs_input_grad[2] else None
+            dw2 = _tn_product(x0, dy) if ctx.needs_input_grad[3] else None
+        return dh, dw1, dx0, dw2
+
+
+class RowsLinear(Linear):
+    """``torch.nn.Linear`` (same parameters, same state dict) for [rows, features] inputs."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.dim() != 2 or not x.is_cuda:
+            return super().forward(x)
+        return _RowsLinear.apply(x, self.weight, self.bias)
+
+
 def glorot_(w: Tensor) -> None:
     a = math.sqrt(6.0 / (w.size(-2) + w.size(-1)))
     with torch.no_grad():
@@ -37,7 +107,7 @@ class GCNConv(torch.nn.Module):
         if normalize:
             raise NotImplementedError("normalise the adjacency once up front (gcn_norm)")
         self.in_channels, self.out_channels = in_channels, out_channels
-        self.lin = Linear(in_channels, out_channels, bias=False)
+        self.lin = RowsLinear(in_channels, out_channels, bias=False)
         self.bias = Parameter(torch.zeros(out_channels)) if bias else None
         self.reset_parameters()
 
@@ -76,6 +146,7 @@ class GCN2Conv(torch.nn.Module):
             self.beta = math.log(theta / layer + 1)
         self.weight1 = Parameter(torch.empty(channels, channels))
         self.weight2 = None if shared_weights else Parameter(torch.empty(channels, channels))
+        self._eye = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -87,17 +158,28 @@ class GCN2Conv(torch.nn.Module):
         """``A x`` (kept un-mixed so that :meth:`forward_after_propagate` takes it)."""
         return spmm(adj_t, x)
 
+    def _folded(self, weight: Tensor, scale: float) -> Tensor:
+        """``scale * (beta * W + (1 - beta) * I)``: the identity part of
+        ``(1 - beta) p + beta p W`` folded into the weight, so that the layer is one GEMM
+        per term and no elementwise pass over the [rows, channels] activations."""
+        eye = self._eye
+        if eye is None or eye.device != weight.device:
+            eye = self._eye = torch.eye(self.channels, device=weight.device, dtype=weight.dtype)
+        return torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta)
+
     def forward_after_propagate(self, h: Tensor, x_0: Tensor) -> Tensor:
         """Everything after the propagation, given ``h = A x`` (models/gcn2.py:257,306)."""
         b = h.size(0)
-        x_0 = x_0[:b]
+        x_0 = x_0 if x_0.size(0) == b else x_0[:b]
         if self.weight2 is None:
             p = torch.add(h * (1 - self.alpha), x_0, alpha=self.alpha)
-            return torch.addmm(p, p, self.weight1, beta=1.0 - self.beta, alpha=self.beta)
-        ax = h * (1 - self.alpha)
-        x0 = x_0 * self.alpha
-        out = torch.addmm(ax, ax, self.weight1, beta=1.0 - self.beta, alpha=self.beta)
-        return out + torch.addmm(x0, x0, self.weight2, beta=1.0 - self.beta, alpha=self.beta)
+            return _TwoTermUpdate.apply(p, self._folded(self.weight1, 1.0), None, None)
+        return _TwoTermUpdate.apply(h, self._folded(self.weight1, 1.0 - self.alpha), x_0,
+                                    self._folded(self.weight2, self.alpha))
+
+    def update_mixed(self, p: Tensor) -> Tensor:
+        """Shared weights, given ``p = (1 - alpha) A x + alpha x_0`` from the kernel epilogue."""
+        return _TwoTermUpdate.apply(p, self._folded(self.weight1, 1.0), None, None)
 
     def forward_no_neighbor(self, x: Tensor, x_0: Tensor) -> Tensor:
         """The layer with the propagation replaced by the identity (models/gcn2.py:159,175)."""
@@ -107,8 +189,8 @@ class GCN2Conv(torch.nn.Module):
         b = adj_t.size(0)
         if self.weight2 is None:
             # the mix (1-alpha) A x + alpha x_0 rides in the aggregation epilogue
-            p = spmm(adj_t, x, scale=1 - self.alpha, add=x_0[:b], add_scale=self.alpha)
-            return torch.addmm(p, p, self.weight1, beta=1.0 - self.beta, alpha=self.beta)
+            return self.update_mixed(spmm(adj_t, x, scale=1 - self.alpha, add=x_0[:b],
+                                          add_scale=self.alpha))
         return self.forward_after_propagate(spmm(adj_t, x), x_0)
 
 
@@ -121,8 +203,8 @@ class SAGEConv(torch.nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.aggr, self.normalize, self.root_weight = aggr, normalize, root_weight
         self.project = False
-        self.lin_l = Linear(in_channels, out_channels, bias=bias)
-        self.lin_r = Linear(in_channels, out_channels, bias=False) if root_weight else None
+        self.lin_l = RowsLinear(in_channels, out_channels, bias=bias)
+        self.lin_r = RowsLinear(in_channels, out_channels, bias=False) if root_weight else None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -133,7 +215,7 @@ class SAGEConv(torch.nn.Module):
     def update(self, agg: Tensor, x_root: Tensor) -> Tensor:
         out = self.lin_l(agg)
         if self.lin_r is not None:
-            out = out + self.lin_r(x_root[:agg.size(0)])
+            out = out + self.lin_r(x_root if x_root.size(0) == agg.size(0) else x_root[:agg.size(0)])
         if self.normalize:
             out = torch.nn.functional.normalize(out, p=2.0, dim=-1)
         return out

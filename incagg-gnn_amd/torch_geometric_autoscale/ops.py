@@ -49,8 +49,12 @@ def _need_cuda(t: Tensor, name: str) -> None:
 # --------------------------------------------------------------------------- aggregation
 def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, n_cols: int,
              reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
-             add_scale: float = 0.0, max_row_nnz: int = -1, out: Optional[Tensor] = None) -> Tensor:
-    """y = scale * reduce_rows(A, x) + add_scale * add   (incagg_spmm_csr_f32)."""
+             add_scale: float = 0.0, max_row_nnz: int = -1, out: Optional[Tensor] = None,
+             x_halo: Optional[Tensor] = None) -> Tensor:
+    """y = scale * reduce_rows(A, [x ; x_halo]) + add_scale * add   (incagg_spmm_csr_f32).
+
+    With ``x_halo`` the source rows ``[x.size(0), n_cols)`` are read from ``x_halo`` -- the
+    concatenation is never materialised."""
     _need_cuda(x, "x")
     dev = x.device
     _rows_f32(x, "x")
@@ -61,9 +65,18 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
         raise ValueError("CSR and x must be on the same device")
     if val is not None and (val.dtype != torch.float32 or val.numel() != col32.numel()):
         raise ValueError("val must be float32 with one entry per edge")
-    if x.size(0) < n_cols:
-        raise ValueError(f"x has {x.size(0)} rows but the adjacency has {n_cols} columns")
     width = x.size(1)
+    n_split = n_cols
+    if x_halo is not None:
+        _rows_f32(x_halo, "x_halo", dev)
+        if x_halo.size(1) != width:
+            raise ValueError("x and x_halo differ in width")
+        n_split = x.size(0)
+        if n_split > n_cols or n_split + x_halo.size(0) < n_cols:
+            raise ValueError(f"x ({x.size(0)} rows) + x_halo ({x_halo.size(0)} rows) do not cover "
+                             f"the {n_cols} columns of the adjacency")
+    elif x.size(0) < n_cols:
+        raise ValueError(f"x has {x.size(0)} rows but the adjacency has {n_cols} columns")
     if add is not None:
         _rows_f32(add, "add", dev)
         if add.size(0) < n_rows or add.size(1) != width:
@@ -76,7 +89,8 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
             raise ValueError("out has the wrong shape")
     with torch.cuda.device(dev):
         check(lib().incagg_spmm_csr_f32(
-            _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), n_rows, n_cols, width,
+            _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(x_halo),
+            0 if x_halo is None else _ld(x_halo), n_split, n_rows, n_cols, width,
             REDUCE[reduce], float(scale), _ptr(add), 0 if add is None else _ld(add),
             float(add_scale), int(max_row_nnz), _ptr(out), _ld(out), _stream_of(dev)))
     return out

@@ -67,6 +67,10 @@ int incagg_check_device_errors(void);
  *
  *   rowptr[n_rows+1], col[nnz]  device int32;  val[nnz] device fp32 or NULL (= 1)
  *   x[n_cols, width]  ld = ldx;  add (may be NULL) [n_rows, width] ld = ldadd
+ *   x_halo (may be NULL): when given, source rows [n_split, n_cols) are read from
+ *     x_halo[c - n_split, :] (ld = ld_halo) instead of x.  This is how a layer consumes
+ *     "fresh in-batch rows + pulled out-of-batch History rows" without materialising
+ *     their concatenation (the torch.cat of models/base.py:426,451).
  *   reduce: INCAGG_REDUCE_SUM | INCAGG_REDUCE_MEAN (divide by max(row length, 1))
  *   max_row_nnz: length of the longest row if the caller knows it, else -1.
  *   y[n_rows, width] ld = ldy; must not alias x.
@@ -80,10 +84,11 @@ int incagg_check_device_errors(void);
  * (device, stream) on the first call that may need it.
  */
 int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
-                        const float *x, int64_t ldx, int64_t n_rows, int64_t n_cols,
-                        int64_t width, int reduce, float scale, const float *add,
-                        int64_t ldadd, float add_scale, int64_t max_row_nnz, float *y,
-                        int64_t ldy, void *stream);
+                        const float *x, int64_t ldx, const float *x_halo, int64_t ld_halo,
+                        int64_t n_split, int64_t n_rows, int64_t n_cols, int64_t width,
+                        int reduce, float scale, const float *add, int64_t ldadd,
+                        float add_scale, int64_t max_row_nnz, float *y, int64_t ldy,
+                        void *stream);
 
 /*
  * Fused incremental aggregate (the fork's contribution):

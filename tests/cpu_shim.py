@@ -16,7 +16,9 @@ def _np(t):
 
 
 def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None, add_scale=0.0,
-              max_row_nnz=-1, out=None):
+              max_row_nnz=-1, out=None, x_halo=None):
+    if x_halo is not None:
+        x = torch.cat([x, x_halo], dim=0)
     y = cp.spmm(_np(rowptr32).astype(np.int64), _np(col32).astype(np.int64), _np(val),
                 _np(x), reduce)
     y = torch.from_numpy(y) * scale
