@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--mode", default="gas", choices=["gas", "vr"],
                     help="push/pull training step (headline) or incremental-aggregation step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the partition-parallel code path even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -133,16 +135,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    sharded = world > 1 or args.force_dist
+    if sharded:
+        if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=dev)
 
     import torch_geometric_autoscale as tga
     from torch_geometric_autoscale import ops, _lib
     from torch_geometric_autoscale.models import GCN2
     from torch_geometric_autoscale.loader import partition_batch
+    from torch_geometric_autoscale import distributed as D
 
     clock = KernelClock()
     clock.wrap(ops)
@@ -161,14 +167,20 @@ def main():
     x_all = torch.randn(n, f_in, device=dev, generator=g)   # features live in HBM
     y_all = torch.randint(0, n_cls, (n,), device=dev, generator=g)
 
-    # partitions owned by this rank (contiguous block of parts => contiguous History rows)
+    # Rank r owns a contiguous block of partitions, i.e. a contiguous block of History rows;
+    # every rank runs the same number of steps, each on one of its own partitions.
+    ctx = D.PartitionContext(ptr) if sharded else None
     parts_lo, parts_hi = rank * args.parts // world, (rank + 1) * args.parts // world
     my_parts = list(range(parts_lo, parts_hi))
-    need = min(len(my_parts), args.steps + args.warmup)
+    need = min(args.parts // world, args.steps + args.warmup)
     loader_data = tga.Data(adj_t=data.adj_t, num_nodes=n)
     batches = []
     for p in my_parts[:need]:
-        sub = partition_batch(loader_data, ptr, [p], in_batch_only=(args.mode == "vr"))
+        if sharded:     # collective: builds the halo exchange plan of the batch
+            sub = D.sharded_partition_batch(loader_data, ptr, [p], ctx,
+                                            in_batch_only=(args.mode == "vr"))
+        else:
+            sub = partition_batch(loader_data, ptr, [p], in_batch_only=(args.mode == "vr"))
         adj = sub.data.adj_t.to(dev)
         t_rowptr = adj.device_csr_t("sum")[0]       # backward CSR, once per batch
         nid_dev = sub.n_id.to(dev)
@@ -186,8 +198,11 @@ def main():
             "x": x_all[nid_dev], "y": y_all[nid_dev[:sub.batch_size]], "edges": step_edges,
         })
 
-    model = GCN2(n, f_in, args.hidden, n_cls, args.layers, alpha=0.1, theta=0.5,
+    table_rows = ctx.local_rows if sharded else n      # row-sharded tables, never replicated
+    model = GCN2(table_rows, f_in, args.hidden, n_cls, args.layers, alpha=0.1, theta=0.5,
                  shared_weights=False, dropout=0.0, device=dev).to(dev)
+    if sharded:
+        model.set_partition_context(ctx)
     g_cpu = torch.Generator().manual_seed(2)
     with torch.no_grad():
         for p_ in model.parameters():
@@ -212,12 +227,14 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = crit(out, bt["y"])
         loss.backward()
+        if sharded:
+            D.allreduce_gradients(model, ctx)
         opt.step()
         return bt["edges"]
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     clock.enabled = True
@@ -226,8 +243,9 @@ def main():
     for i in range(args.steps):
         edges += step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     clock.enabled = False
     _lib.check_device_errors()
@@ -255,7 +273,10 @@ def main():
                             f"partitions, one partition per step, {args.mode} training step, "
                             "History tables resident in HBM",
                 "batch_rows": bt["b"], "batch_rows_with_halo": int(bt["n_id"].numel()),
-                "batch_edges": bt["adj"].nnz(), "parallelism": f"partition-parallel x{world}",
+                "batch_edges": bt["adj"].nnz(),
+                "parallelism": f"partition-parallel x{world}" + (
+                    ", row-sharded History tables, one all-to-all of halo rows per layer, "
+                    "flat gradient all-reduce" if sharded else ""),
                 "setup_seconds": round(setup_s, 1),
             },
         }
@@ -276,7 +297,7 @@ def main():
                              int(b_["n_id"].numel())))
             line["cpu_baseline"] = cpu_baseline(host, args.layers, args.hidden, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -20,6 +20,7 @@ from .utils import compute_micro_f1, gen_masks, dropout, index2mask  # noqa: E40
 from .loader import SubgraphLoader, EvalSubgraphLoader, SubData  # noqa: E402
 from .aggregate import spmm, incagg_aggregate  # noqa: E402
 from . import models  # noqa: E402
+from . import distributed  # noqa: E402
 
 __version__ = '0.1.0'
 

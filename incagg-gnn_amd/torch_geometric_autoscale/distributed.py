@@ -1,0 +1,221 @@
+"""Partition-parallel execution over the GPUs of one node: one process per GPU,
+``torch.distributed`` (RCCL over xGMI on the GPU box, gloo in the CPU tests).
+
+The reference is single-process (no collective anywhere in its tree); this module adds
+the sharding its data layout already implies:
+
+* METIS-style partitions are contiguous id ranges (metis.py:32-33) and batches are unions
+  of whole partitions (loader.py:135-138), so rank ``r`` of ``G`` owns partitions
+  ``[r P / G, (r+1) P / G)`` = the contiguous History rows ``[row_lo, row_hi)`` of every
+  table.  Tables are row-sharded, never replicated; pushes are always local.
+* A batch's out-of-batch rows may live on peers.  They are fetched with ONE all-to-all per
+  layer (each GPU serves every peer directly, so all xGMI links carry traffic at once;
+  nothing funnels through a ring): the owner gathers the requested rows out of its shard
+  with the History gather kernel, ``all_to_all_single`` moves them, and they land
+  directly in the tail of the halo buffer the aggregation kernel reads -- the batch's
+  out-of-batch ids are re-ordered at build time to ``[own rank | peer 0 | peer 1 | ...]``
+  precisely so that no scatter is needed on arrival.
+* The incremental-aggregation training step touches in-batch rows only
+  (loader.py:194-214), so it needs no halo traffic at all; weight gradients are summed
+  with one flat all-reduce (a few MB).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import ops
+from .data import Data
+from .loader import SubData, partition_batch
+from .sparse import SparseTensor
+
+
+class PartitionContext:
+    """Who owns which partitions / History rows."""
+
+    def __init__(self, ptr: Tensor, group=None, rank: Optional[int] = None,
+                 world: Optional[int] = None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.ptr = ptr
+        n_parts = ptr.numel() - 1
+        cuts = [r * n_parts // self.world for r in range(self.world + 1)]
+        self.part_bounds = cuts
+        self.row_bounds = ptr[torch.tensor(cuts)].clone()          # [world + 1] global row ids
+        self.part_lo, self.part_hi = cuts[self.rank], cuts[self.rank + 1]
+        self.row_lo, self.row_hi = int(self.row_bounds[self.rank]), int(self.row_bounds[self.rank + 1])
+
+    @property
+    def local_rows(self) -> int:
+        return self.row_hi - self.row_lo
+
+    @property
+    def local_parts(self) -> List[int]:
+        return list(range(self.part_lo, self.part_hi))
+
+    def owner_of(self, n_id: Tensor) -> Tensor:
+        return torch.bucketize(n_id, self.row_bounds[1:].to(n_id.device), right=True)
+
+    def max_over_ranks(self, value: int) -> int:
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.int64, device=self._comm_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t)
+
+    def _comm_device(self):
+        backend = dist.get_backend(self.group)
+        return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+
+class HaloPlan:
+    """The exchange pattern of one batch: which of its out-of-batch rows come from which
+    rank, and which local rows this rank serves to each peer while the batch is in flight.
+    Built collectively (every rank calls :func:`build_halo_plan` the same number of times)."""
+
+    def __init__(self, ctx: PartitionContext, own_local: Tensor, recv_counts: List[int],
+                 serve_local: Tensor, send_counts: List[int]):
+        self.ctx = ctx
+        self.own_local = own_local          # local row ids of out-of-batch rows this rank owns
+        self.recv_counts = recv_counts      # rows arriving from each rank (0 for itself)
+        self.serve_local = serve_local      # local row ids to send, grouped by destination rank
+        self.send_counts = send_counts
+        self.n_halo = own_local.numel() + sum(recv_counts)
+        self._dev = {}
+
+    def _on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (self.own_local.to(device), self.serve_local.to(device))
+        return self._dev[key]
+
+    def exchange(self, shard: Tensor, width: Optional[int] = None,
+                 out: Optional[Tensor] = None) -> Optional[Tensor]:
+        """The batch's out-of-batch rows of one (row-sharded) table, in plan order.
+        Collective: every rank of the group calls it once per (round, layer)."""
+        device = out.device if out is not None else (
+            shard.device if shard.is_cuda or not torch.cuda.is_available()
+            else torch.device("cuda", torch.cuda.current_device()))
+        own_local, serve_local = self._on(device)
+        f = shard.size(1)
+        if out is None:
+            out = torch.empty((self.n_halo, f), dtype=shard.dtype, device=device)
+        n_own = own_local.numel()
+        if n_own:
+            ops.gather_rows(shard, own_local, out=out[:n_own], device=device)
+        if self.ctx.world > 1:
+            send = ops.gather_rows(shard, serve_local, device=device) if serve_local.numel() \
+                else torch.empty((0, f), dtype=shard.dtype, device=device)
+            recv = out[n_own:self.n_halo]
+            dist.all_to_all_single(recv, send, self.recv_counts, self.send_counts,
+                                   group=self.ctx.group)
+        if self.n_halo == 0:
+            return None
+        return out[:self.n_halo] if width is None else out[:self.n_halo, :width]
+
+
+def build_halo_plan(ctx: PartitionContext, halo_ids: Tensor) -> Tuple[HaloPlan, Tensor]:
+    """``halo_ids``: global ids of a batch's out-of-batch nodes (any order; may be empty).
+    Returns the plan and the permutation ``order`` such that ``halo_ids[order]`` is the
+    order in which :meth:`HaloPlan.exchange` delivers the rows: own rank first, then the
+    peers in rank order.  Collective."""
+    owner = ctx.owner_of(halo_ids)
+    # sort key: own rank -> -1, others keep their rank
+    key = torch.where(owner == ctx.rank, torch.full_like(owner, -1), owner)
+    order = torch.argsort(key, stable=True)
+    sorted_ids, sorted_owner = halo_ids[order], owner[order]
+    own_mask = sorted_owner == ctx.rank
+    own_local = sorted_ids[own_mask] - ctx.row_lo
+    remote_ids = sorted_ids[~own_mask]
+    recv_counts = torch.bincount(sorted_owner[~own_mask], minlength=ctx.world).tolist()
+    recv_counts[ctx.rank] = 0
+    if ctx.world == 1:
+        return HaloPlan(ctx, own_local, [0], torch.zeros(0, dtype=torch.int64), [0]), order
+    dev = ctx._comm_device()
+    want = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
+    serve = torch.empty_like(want)
+    dist.all_to_all_single(serve, want, group=ctx.group)
+    send_counts = serve.tolist()
+    req = remote_ids.to(dev)
+    asked = torch.empty(int(sum(send_counts)), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(asked, req, send_counts, recv_counts, group=ctx.group)
+    serve_local = asked.cpu() - ctx.row_lo
+    if serve_local.numel() and (int(serve_local.min()) < 0 or int(serve_local.max()) >= ctx.local_rows):
+        raise RuntimeError("a peer requested rows this rank does not own")
+    return HaloPlan(ctx, own_local, recv_counts, serve_local, send_counts), order
+
+
+def sharded_partition_batch(data: Data, ptr: Tensor, part_ids, ctx: PartitionContext,
+                            in_batch_only: bool = False) -> SubData:
+    """:func:`partition_batch` for partition-parallel runs.  The out-of-batch ids are
+    re-ordered to the plan's delivery order (and the adjacency's columns relabelled to
+    match); the plan rides on ``adj_t._halo_plan``.  ``part_ids`` may be empty (a rank
+    that has run out of batches still has to serve its peers).  Collective unless
+    ``in_batch_only``."""
+    if len(part_ids) == 0:
+        if in_batch_only:
+            return None
+        plan, _ = build_halo_plan(ctx, torch.zeros(0, dtype=torch.int64))
+        ghost = SparseTensor(rowptr=torch.zeros(1, dtype=torch.int64),
+                             col=torch.zeros(0, dtype=torch.int64), sparse_sizes=(0, 0))
+        ghost._halo_plan = plan
+        empty = torch.zeros(0, dtype=torch.int64)
+        return SubData(data.__class__(adj_t=ghost), 0, empty, empty, empty)
+    sub = partition_batch(data, ptr, part_ids, in_batch_only=in_batch_only)
+    if in_batch_only:
+        return sub
+    b, n_id = sub.batch_size, sub.n_id
+    plan, order = build_halo_plan(ctx, n_id[b:])
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel())
+    rowptr, col, value = sub.data.adj_t.csr()
+    new_col = torch.where(col < b, col, b + inv[(col - b).clamp(min=0)])
+    adj_t = SparseTensor(rowptr=rowptr, col=new_col, value=value,
+                         sparse_sizes=sub.data.adj_t.sparse_sizes(), is_sorted=True)
+    adj_t._halo_plan = plan
+    new_n_id = torch.cat([n_id[:b], n_id[b:][order]])
+    out = data.__class__(adj_t=adj_t)
+    for k, v in sub.data:
+        if k != "adj_t" and isinstance(v, Tensor) and v.dim() > 0 and v.size(0) == n_id.numel():
+            out[k] = torch.cat([v[:b], v[b:][order]])
+    return SubData(out, b, new_n_id, sub.offset, sub.count)
+
+
+def sharded_eval_batches(data: Data, ptr: Tensor, ctx: PartitionContext,
+                         batch_size: int = 1) -> List[SubData]:
+    """This rank's share of the evaluation batches (groups of ``batch_size`` consecutive own
+    partitions), padded with empty batches so that every rank runs the same number of
+    exchange rounds.  Collective."""
+    parts = ctx.local_parts
+    groups = [parts[i:i + batch_size] for i in range(0, len(parts), batch_size)]
+    rounds = ctx.max_over_ranks(len(groups))
+    groups += [[] for _ in range(rounds - len(groups))]
+    return [sharded_partition_batch(data, ptr, g, ctx) for g in groups]
+
+
+def allreduce_gradients(module: torch.nn.Module, ctx: PartitionContext) -> None:
+    """Mean of the weight gradients over the ranks, as ONE flat all-reduce (the models here
+    have a few MB of parameters: a single bucket is the right granularity)."""
+    if ctx.world == 1:
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=ctx.group)
+    flat.div_(ctx.world)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def broadcast_parameters(module: torch.nn.Module, ctx: PartitionContext, src: int = 0) -> None:
+    """Replicates rank ``src``'s weights (and batch-norm statistics) on every rank."""
+    if ctx.world == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src, group=ctx.group)

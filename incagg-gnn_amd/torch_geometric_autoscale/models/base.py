@@ -67,6 +67,10 @@ class ScalableGNN(torch.nn.Module):
         self.__out: Optional[Tensor] = None
         # use one launch for A (x - M_in) + M_ag (True) or subtract first (False)
         self.fused_incagg = True
+        # partition-parallel runs: a distributed.PartitionContext; the tables then hold only
+        # this rank's rows (construct the model with num_nodes = ctx.local_rows)
+        self.partition_ctx = None
+        self._current_plan = None
 
     # ------------------------------------------------------------------ placement
     @property
@@ -95,6 +99,20 @@ class ScalableGNN(torch.nn.Module):
             history.reset_parameters()
         for history in self.histories_ag:
             history.reset_parameters()
+
+    def set_partition_context(self, ctx) -> "ScalableGNN":
+        """Switches to partition-parallel mode (see ``distributed.py``): History row ids
+        become ``global id - ctx.row_lo`` and out-of-batch rows owned by peers arrive
+        through the batch's halo plan."""
+        if ctx is not None and ctx.local_rows != self.num_nodes:
+            raise ValueError(f"the tables hold {self.num_nodes} rows but this rank owns "
+                             f"{ctx.local_rows}")
+        self.partition_ctx = ctx
+        return self
+
+    def _local(self, offset: Optional[Tensor]) -> Optional[Tensor]:
+        ctx = self.partition_ctx
+        return offset if ctx is None or offset is None else offset - ctx.row_lo
 
     # ------------------------------------------------------------------ hooks
     agg_reduce = "sum"
@@ -157,6 +175,14 @@ class ScalableGNN(torch.nn.Module):
             warnings.warn('Asynchronous I/O disabled, although history and '
                           'model sit on different devices.')
 
+        self._current_plan = getattr(adj_t, "_halo_plan", None)
+        if self.partition_ctx is not None:
+            if self._async:
+                raise NotImplementedError("partition-parallel runs keep their table shards in HBM")
+            if use_aggregation and self._current_plan is None and n_id is not None \
+                    and n_id.numel() > (batch_size or 0):
+                raise RuntimeError("partition-parallel batches must come from "
+                                   "distributed.sharded_partition_batch (no halo plan attached)")
         if self._async and use_aggregation:
             for hist in self.histories[1:]:
                 self.pool.async_pull(hist.emb, None, None, n_id[batch_size:])
@@ -243,6 +269,12 @@ class ScalableGNN(torch.nn.Module):
             out, _ = self.push_and_pull(history, x, batch_size, n_id, offset, count)
             return out, None
         x = x if x.size(0) == batch_size else x[:batch_size]
+        if self.partition_ctx is not None:
+            # push into the local shard first, then serve / fetch: peers asking for rows of
+            # this very batch get the fresh values
+            history.push(x.detach(), n_id[:batch_size], self._local(offset), count)
+            plan = self._current_plan
+            return x, (None if plan is None else plan.exchange(history.emb))
         if not self._async:
             history.push(x.detach(), n_id[:batch_size], offset, count)
             halo = history.pull(n_id[batch_size:]) if n_id.numel() > batch_size else None
@@ -287,8 +319,10 @@ class ScalableGNN(torch.nn.Module):
             m_ag = self.pool_ag.synchronize_pull()[:batch_size, :width]
             return m_in, m_ag
         if offset is not None and count is not None:
-            m_in = self.histories[layer].pull_chunks(offset, count)
-            m_ag = self.histories_ag[layer].pull_chunks(offset, count)
+            m_in = self.histories[layer].pull_chunks(self._local(offset), count)
+            m_ag = self.histories_ag[layer].pull_chunks(self._local(offset), count)
+        elif self.partition_ctx is not None:
+            raise RuntimeError("partition-parallel batches address their rows by (offset, count)")
         else:
             idx = n_id[:batch_size].to(self.emb_device)
             m_in = self.histories[layer].pull(idx)
@@ -408,18 +442,20 @@ class ScalableGNN(torch.nn.Module):
                 src += c
 
     def _pull_layer_input(self, history: History, batch_size: int, n_id: Tensor, offset: Tensor,
-                          count: Tensor) -> Tensor:
+                          count: Tensor, plan=None) -> Tensor:
         """[in-batch rows by chunks ; out-of-batch rows by index] of one table, on the
         compute device (what models/gcn.py:378-385 gets from the pool)."""
         m = n_id.numel()
-        if self.device.type != 'cuda':
+        if self.device.type != 'cuda' and self.partition_ctx is None:
             emb = history.emb
             ib = torch.cat([emb[o:o + c] for o, c in zip(offset.tolist(), count.tolist())])
             return torch.cat([ib, emb.index_select(0, n_id[batch_size:])])[:m]
         out = torch.empty((m, history.embedding_dim), dtype=history.emb.dtype, device=self.device)
-        ops.copy_row_chunks(out, history.emb, offset, count, packed_is_src=False,
+        ops.copy_row_chunks(out, history.emb, self._local(offset), count, packed_is_src=False,
                             device=self.device)
-        if m > batch_size:
+        if self.partition_ctx is not None:
+            plan.exchange(history.emb, out=out[batch_size:])
+        elif m > batch_size:
             ops.gather_rows(history.emb, n_id[batch_size:].to(self.device), out=out[batch_size:],
                             device=self.device)
         return out
@@ -431,8 +467,12 @@ class ScalableGNN(torch.nn.Module):
         pool = self.pool if use_pool else None
         pool_ag = self.pool_ag if use_pool else None
         last = self.num_layers - 1
+        sharded = self.partition_ctx is not None
+        if sharded and use_pool:
+            raise NotImplementedError("partition-parallel runs keep their table shards in HBM")
 
         def run_layer(i, x, adj_t, batch_size, offset, count, state):
+            offset = self._local(offset)
             agg = self._aggregate(adj_t, x) if use_aggregation else x[:batch_size]
             if with_aggregates:
                 self._push_rows(self.histories_ag[i].emb, agg, offset, count, pool_ag)
@@ -441,10 +481,13 @@ class ScalableGNN(torch.nn.Module):
             self._push_rows(target, out, offset, count, pool)
 
         for data, batch_size, n_id, offset, count, state in batches:
+            if batch_size == 0:      # padding batch of a partition-parallel run
+                continue
             adj_t = data.adj_t.to(self.device)
             x = self._embed(data.x.to(self.device), state, batch_size)
             if with_aggregates:
-                self._push_rows(self.histories[0].emb, x[:batch_size], offset, count, pool)
+                self._push_rows(self.histories[0].emb, x[:batch_size], self._local(offset), count,
+                                pool)
             run_layer(0, x, adj_t, batch_size, offset, count, state)
         if use_pool:
             pool.synchronize_push()
@@ -455,11 +498,16 @@ class ScalableGNN(torch.nn.Module):
                 for _, batch_size, n_id, offset, count, _ in batches:
                     pool.async_pull(self.histories[i].emb, offset, count, n_id[batch_size:])
             for data, batch_size, n_id, offset, count, state in batches:
+                plan = getattr(data.adj_t, "_halo_plan", None) if sharded else None
+                if batch_size == 0:  # nothing of our own left, but peers still need serving
+                    plan.exchange(self.histories[i].emb)
+                    continue
                 adj_t = data.adj_t.to(self.device)
                 if use_pool:
                     x = pool.synchronize_pull()[:n_id.numel()]
                 else:
-                    x = self._pull_layer_input(self.histories[i], batch_size, n_id, offset, count)
+                    x = self._pull_layer_input(self.histories[i], batch_size, n_id, offset, count,
+                                               plan)
                 run_layer(i, x, adj_t, batch_size, offset, count, state)
                 if use_pool:
                     pool.free_pull()

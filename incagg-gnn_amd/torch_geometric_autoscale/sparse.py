@@ -158,6 +158,13 @@ class SparseTensor:
                                        and device.index is None):
             return self
         if device.type == "cuda":
+            if device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            # One upload per adjacency: evaluation batches are static and are revisited
+            # once per layer and per epoch, and HBM has room for all of them.
+            copies = self.__dict__.setdefault("_device_copies", {})
+            if device in copies:
+                return copies[device]
             # Convert to the device format on the host, then upload 4-byte indices.
             out = SparseTensor.__new__(SparseTensor)
             out._sizes = self._sizes
@@ -173,6 +180,9 @@ class SparseTensor:
             out._transposed = {}
             out._max_row_nnz = self.max_row_nnz()
             out.storage = _Storage(out)
+            if hasattr(self, "_halo_plan"):
+                out._halo_plan = self._halo_plan
+            copies[device] = out
             return out
         rowptr, col, value = self.csr()
         out = SparseTensor(rowptr=rowptr.to(device), col=col.to(device),
@@ -192,6 +202,7 @@ class SparseTensor:
         out.__dict__.update(self.__dict__)
         out._value = value
         out._transposed = {}
+        out.__dict__.pop("_unweighted_view", None)
         out._host = None if self._host is None else self._host.set_value(
             None if value is None else value.cpu())
         out.storage = _Storage(out)

@@ -77,7 +77,7 @@ int incagg_check_device_errors(void);
  *   width <= 1024 when every pointer is 16-byte aligned and every ld a multiple
  *   of 4, else width <= 256.
  *
- * Rows longer than 512 edges are cut into 256-edge slices that are summed onto
+ * Rows longer than 128 edges are cut into 64-edge slices that are summed onto
  * the row with fp32 atomics by a second launch (skipped when max_row_nnz says
  * there is no such row), so such rows are reproducible only up to fp32 rounding
  * order.  The slice queue is device memory the library allocates once per

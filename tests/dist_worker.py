@@ -1,0 +1,63 @@
+"""Worker of tests/test_distributed_cpu.py: one rank of a partition-parallel run on the CPU
+(gloo).  The HIP entry points are swapped for the CPU oracle (tests/cpu_shim.py), so what
+is exercised is the sharding, the halo plans, the all-to-all routing and the gradient
+all-reduce.  Launched with torch.distributed.run; writes its results to argv[1]."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT, os.path.join(ROOT, "incagg-gnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import model_cases as mc  # noqa: E402
+from cpu_shim import cpu_kernels  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    names = sys.argv[2].split(",")
+    dist.init_process_group("gloo")
+    from torch_geometric_autoscale import distributed as D
+    data, ptr = mc.make_graph()
+    ctx = D.PartitionContext(ptr)
+    result = {"row_lo": ctx.row_lo, "row_hi": ctx.row_hi}
+    with cpu_kernels():
+        for name in names:
+            model = mc.make_model(name, data, data.x.size(1), 5, emb_device="cpu",
+                                  num_nodes=ctx.local_rows)
+            model.set_partition_context(ctx)
+            model.eval()
+            batches = D.sharded_eval_batches(data, ptr, ctx, batch_size=1)
+            out = model.mini_inference_vr(batches)
+            result[f"{name}/out"] = out.clone()
+            for i in range(model.num_layers):
+                result[f"{name}/hist{i}"] = model.histories[i].emb.clone()
+                result[f"{name}/hist_ag{i}"] = model.histories_ag[i].emb.clone()
+            # push/pull forward + backward on this rank's first partition, then the all-reduce
+            sub = D.sharded_partition_batch(data, ptr, [ctx.part_lo], ctx)
+            b = sub.batch_size
+            ret = model(sub.data.x, sub.data.adj_t, b, sub.n_id, sub.offset, sub.count)
+            result[f"{name}/gas_out"] = ret["out"].detach().clone()
+            loss = torch.nn.functional.cross_entropy(ret["out"], sub.data.y[:b])
+            model.zero_grad()
+            loss.backward()
+            D.allreduce_gradients(model, ctx)
+            result[f"{name}/grad"] = torch.cat([p.grad.reshape(-1) for p in model.parameters()
+                                                if p.grad is not None])
+            # incremental-aggregation step: no halo traffic at all
+            sub = D.sharded_partition_batch(data, ptr, [ctx.part_lo], ctx, in_batch_only=True)
+            ret = model.VR_call(sub.data.x, sub.data.adj_t, sub.batch_size, sub.n_id, sub.offset,
+                                sub.count)
+            result[f"{name}/vr_out"] = ret["out"].detach().clone()
+    torch.save(result, os.path.join(out_dir, f"rank{ctx.rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,12 +32,13 @@ MODEL_CASES = {
 }
 
 
-def make_model(name, data, f_in, n_cls, emb_device, pool_size=None, buffer_size=None):
+def make_model(name, data, f_in, n_cls, emb_device, pool_size=None, buffer_size=None,
+               num_nodes=None):
     from torch_geometric_autoscale import models
     case = MODEL_CASES[name]
     cls = dict(gcn=models.GCN, sage=models.GraphSAGE, gcn2=models.GCN2, appnp=models.APPNP)[case["kind"]]
     torch.manual_seed(7)
-    model = cls(num_nodes=data.num_nodes, in_channels=f_in, out_channels=n_cls,
+    model = cls(num_nodes=data.num_nodes if num_nodes is None else num_nodes, in_channels=f_in, out_channels=n_cls,
                 pool_size=pool_size, buffer_size=buffer_size, device=emb_device, **case["cfg"])
     # non-trivial batch-norm statistics so that eval-mode bn is not the identity
     for bn in getattr(model, "bns", []):

@@ -1,0 +1,91 @@
+"""Partition-parallel path with world_size 2 and 4 (uneven shares, padding rounds) on the CPU (gloo): the row-sharded
+History tables after a refresh sweep must equal the single-process tables, the push/pull
+forward of a rank's partition must equal the single-process forward of that partition, and
+the all-reduced gradient must be the mean of the per-rank gradients."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import model_cases as mc
+from cpu_shim import cpu_kernels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ["gcn2", "sage", "appnp"]
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_run_matches_single_process(world, tmp_path):
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), ",".join(NAMES)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    ranks = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+
+    from torch_geometric_autoscale.loader import partition_batch
+    import torch_geometric_autoscale as tga
+    data, ptr = mc.make_graph()
+    n_parts = ptr.numel() - 1
+    with cpu_kernels():
+        for name in NAMES:
+            model = mc.make_model(name, data, data.x.size(1), 5, emb_device="cpu")
+            model.eval()
+            loader = tga.EvalSubgraphLoader(data, ptr, batch_size=1, log=False)
+            out = model.mini_inference_vr(loader)
+            grads, cover = [], []
+            for r, res in enumerate(ranks):
+                lo, hi = res["row_lo"], res["row_hi"]
+                cover.append((lo, hi))
+                np.testing.assert_allclose(res[f"{name}/out"].numpy(), out[lo:hi].numpy(), **TOL)
+                for i in range(model.num_layers):
+                    np.testing.assert_allclose(res[f"{name}/hist{i}"].numpy(),
+                                               model.histories[i].emb[lo:hi].numpy(), **TOL)
+                    np.testing.assert_allclose(res[f"{name}/hist_ag{i}"].numpy(),
+                                               model.histories_ag[i].emb[lo:hi].numpy(), **TOL)
+                part = r * n_parts // world
+                sub = partition_batch(data, ptr, [part])
+                b = sub.batch_size
+                ret = model(sub.data.x, sub.data.adj_t, b, sub.n_id, sub.offset, sub.count)
+                np.testing.assert_allclose(res[f"{name}/gas_out"].numpy(),
+                                           ret["out"].detach().numpy(), **TOL)
+                loss = torch.nn.functional.cross_entropy(ret["out"], sub.data.y[:b])
+                model.zero_grad()
+                loss.backward()
+                grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()
+                                        if p.grad is not None]))
+                sub = partition_batch(data, ptr, [part], in_batch_only=True)
+                ret = model.VR_call(sub.data.x, sub.data.adj_t, sub.batch_size, sub.n_id,
+                                    sub.offset, sub.count)
+                np.testing.assert_allclose(res[f"{name}/vr_out"].numpy(),
+                                           ret["out"].detach().numpy(), **TOL)
+            assert cover[0][0] == 0 and cover[-1][1] == data.num_nodes
+            assert all(a[1] == b_[0] for a, b_ in zip(cover, cover[1:]))
+            mean_grad = torch.stack(grads).mean(0).numpy()
+            for res in ranks:                      # identical on every rank after the all-reduce
+                np.testing.assert_allclose(res[f"{name}/grad"].numpy(), mean_grad, rtol=1e-4,
+                                           atol=1e-6)
+
+
+def test_halo_plan_orders_own_rows_first():
+    from torch_geometric_autoscale import distributed as D
+    ptr = torch.tensor([0, 10, 20, 30, 40])
+    ctx = D.PartitionContext(ptr, rank=1, world=2)
+    assert (ctx.row_lo, ctx.row_hi, ctx.local_parts) == (20, 40, [2, 3])
+    assert ctx.owner_of(torch.tensor([0, 19, 20, 39])).tolist() == [0, 0, 1, 1]
+    one = D.PartitionContext(ptr, rank=0, world=1)
+    plan, order = D.build_halo_plan(one, torch.tensor([33, 2, 17]))
+    assert order.tolist() == [0, 1, 2] and plan.own_local.tolist() == [33, 2, 17]
+    assert plan.n_halo == 3 and plan.recv_counts == [0]
