@@ -95,6 +95,20 @@ class KernelClock:
                 "algo_bytes_per_launch": algo / len(ms)}
 
 
+def pmc_traffic(args):
+    """Fabric bytes per aggregation launch from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs of this very
+    command, FETCH_SIZE doubled as gfx950 requires).  Counters cannot be read from inside
+    the process, so the figure is only reported for the workload it was measured on."""
+    default = (args.dataset, args.parts, args.layers, args.hidden, args.scale, args.cross,
+               args.mode) == ("products", 150, 8, 256, 1.0, 0.15, "gas")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not default or not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(batches, layers, width, seconds):
     """The CPU oracle's aggregation (forward + transposed) on the same batches, all host
     cores the box grants (OMP), for about `seconds` of work."""
@@ -283,7 +297,7 @@ def main():
         if ks:
             line["roofline"] = {
                 "bound": "hbm", "achieved": ks["algo_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ks["algo_GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                "frac": ks["algo_GBps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(args),
                 "kernel": "spmm_rows_kernel (+ spmm_hub_kernel), forward and transposed launches",
                 "avg_launch_ms": ks["avg_ms"], "launches": ks["launches"],
                 "algorithmic_bytes_per_launch": ks["algo_bytes_per_launch"],
