@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--mode", default="gas", choices=["gas", "vr"],
                     help="push/pull training step (headline) or incremental-aggregation step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", choices=["auto", "on", "off"], default="auto",
+                    help="also time one full refresh sweep (mini_inference_vr) over all "
+                         "partitions; auto = only on a single GPU")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the partition-parallel code path even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -272,6 +275,32 @@ def main():
         dist.all_reduce(e_sum, op=dist.ReduceOp.SUM)
         elapsed, edges = float(t_max), float(e_sum)
 
+    # ---- epoch time, part (ii): one layer-wise refresh sweep over every partition
+    # (outside the timed region above; it is reported next to the headline value)
+    sweep_s = sweep_edges = None
+    if args.sweep == "on" or (args.sweep == "auto" and not sharded):
+        model.eval()
+        feat = tga.Data(adj_t=data.adj_t, num_nodes=n)
+        if sharded:
+            evals = D.sharded_eval_batches(feat, ptr, ctx)
+        else:
+            evals = [partition_batch(feat, ptr, [p]) for p in range(args.parts)]
+        for sub in evals:                       # features of each batch resident in HBM
+            if sub.batch_size:
+                sub.data.x = x_all[sub.n_id.to(dev)]
+                sub.data.adj_t.to(dev)
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+        t0 = time.perf_counter()
+        model.mini_inference_vr(evals)
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+        sweep_s = time.perf_counter() - t0
+        sweep_edges = args.layers * sum(sub.data.adj_t.nnz() for sub in evals)
+        _lib.check_device_errors()
+
     ks = clock.summary()
     if rank == 0:
         bt = batches[0]
@@ -292,6 +321,14 @@ def main():
                     ", row-sharded History tables, one all-to-all of halo rows per layer, "
                     "flat gradient all-reduce" if sharded else ""),
                 "setup_seconds": round(setup_s, 1),
+            },
+            "epoch": {
+                "train_epoch_seconds": elapsed / args.steps * (args.parts // world),
+                "refresh_sweep_seconds": sweep_s,
+                "refresh_sweep_edges_per_s": None if not sweep_s else sweep_edges / sweep_s,
+                "note": "training epoch = (partitions per GPU) x measured step time; the sweep is "
+                        "one mini_inference_vr over this rank's partitions (forward only, both "
+                        "History kinds refreshed)",
             },
         }
         if ks:
