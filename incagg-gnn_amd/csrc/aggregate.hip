@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
 
 namespace incagg {
@@ -272,6 +273,265 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_hub_kernel(const S
   }
 }
 
+// ---------------------------------------------------------------- feature-sliced variant
+// The 8 XCDs of an MI355X have private L2s.  With whole rows per wave, a source row that
+// is referenced from destination rows running on different XCDs is fetched into every one
+// of those L2s (measured: fabric traffic ~4x the distinct source bytes at 7 references per
+// source row).  Here the FEATURE dimension is cut into 128-byte slices and slice s is
+// processed only by workgroups with blockIdx % n_slices == s, i.e. (with round-robin
+// dispatch) by one XCD: every byte of the source matrix then has exactly one home L2 and the
+// per-XCD working set shrinks by the number of slices.  Placement is a speed matter only.
+//
+// A wave works on one destination row and one slice: 8 lanes cover the 128 bytes of a
+// gathered piece (one full cache line per edge), the 8 lane groups take 8 different
+// edges per load instruction, and the groups are summed with cross-lane shuffles at the end.
+constexpr int kSliceFloats = 32;
+
+__device__ __forceinline__ f4 shfl_xor4(f4 v, int m) {
+  f4 r;
+  r.x = __shfl_xor(v.x, m); r.y = __shfl_xor(v.y, m);
+  r.z = __shfl_xor(v.z, m); r.w = __shfl_xor(v.w, m);
+  return r;
+}
+
+// Sum over edges [rs, re) of val[e] * (x[col[e], piece] (- m_in[col[e], piece])), for the
+// lane's 16-byte part of the piece; the result still has to be summed over the 8 lane
+// groups.  Indices of the next 8*R edges are loaded while the current gathers are in flight.
+// Column ids / weights of the 64-edge window starting at e0 (lane l: edge e0 + l), one
+// coalesced load each; edges at or beyond `re` get weight 0.
+__device__ __forceinline__ void load_window(const SpmmArgs &a, int e0, int re, int lane, int &c,
+                                            float &w) {
+  // Lane 8 g + j holds window edge 8 j + g: round j of lane group g (see gather_window).
+  // The 64 addresses still fall into the same two cache lines, so the load stays coalesced.
+  // Lanes beyond the row's end re-read its last edge with weight 0, so every lane holds a
+  // real neighbour and the gather loop needs no per-lane guards.  (re > e0 always.)
+  const int slot = e0 + 8 * (lane & 7) + (lane >> 3);
+  const int e = min(slot, re - 1);
+  c = a.col[e];
+  w = a.val ? a.val[e] : 1.0f;
+  if (slot >= re) w = 0.f;
+  if ((unsigned)c >= (unsigned)a.n_cols) {  // never fault on a bad id
+    *a.err = 1;
+    c = 0;
+    w = 0.f;
+  }
+}
+
+// Broadcast of lane 8 * (l / 8) + R inside every group of 8 lanes: a ds_swizzle in
+// bit-mask mode (and = 0b11000, or = R), which needs no address register.
+template <int R>
+__device__ __forceinline__ int group_bcast(int v) {
+  return __builtin_amdgcn_ds_swizzle(v, (R << 5) | 0x18);
+}
+
+// Rounds [R0, R0 + N) of a window: in round r lane group g (8 lanes = the 128 bytes of one
+// piece) gathers window edge 8 r + g, so one load instruction fetches 8 different source
+// rows; all N gathers are issued before the first FMA.  The indices reach the group through
+// the cross-lane network: the vector-memory pipe only sees the row gathers.
+// WIDE: row offsets need 64 bits or the source is split in two matrices; otherwise a
+// 32-bit byte offset per lane on top of a scalar base is enough.
+template <bool INCAGG, bool WIDE, int R0, int N>
+__device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float my_w, int coloff,
+                                              f4 &acc) {
+  int c[N];
+  float w[N];
+  f4 xv[N], mv[N];
+#pragma unroll
+  for (int r = 0; r < N; r++) {
+    // (template recursion keeps the swizzle pattern an immediate)
+    c[r] = r == 0 ? group_bcast<R0>(my_c) : r == 1 ? group_bcast<R0 + 1>(my_c)
+         : r == 2 ? group_bcast<R0 + 2>(my_c) : r == 3 ? group_bcast<R0 + 3>(my_c)
+         : r == 4 ? group_bcast<R0 + 4>(my_c) : r == 5 ? group_bcast<R0 + 5>(my_c)
+         : r == 6 ? group_bcast<R0 + 6>(my_c) : group_bcast<R0 + 7>(my_c);
+    const int wi = __float_as_int(my_w);
+    w[r] = __int_as_float(
+        r == 0 ? group_bcast<R0>(wi) : r == 1 ? group_bcast<R0 + 1>(wi)
+        : r == 2 ? group_bcast<R0 + 2>(wi) : r == 3 ? group_bcast<R0 + 3>(wi)
+        : r == 4 ? group_bcast<R0 + 4>(wi) : r == 5 ? group_bcast<R0 + 5>(wi)
+        : r == 6 ? group_bcast<R0 + 6>(wi) : group_bcast<R0 + 7>(wi));
+  }
+#pragma unroll
+  for (int r = 0; r < N; r++) {
+    if constexpr (WIDE) {
+      const float *xr = c[r] < a.split ? a.x + (size_t)c[r] * a.ldx
+                                       : a.x2 + (size_t)(c[r] - a.split) * a.ldx2;
+      xv[r] = ldv<4>(xr + coloff);
+      if (INCAGG) mv[r] = ldv<4>(a.m_in + (size_t)c[r] * a.ldin + coloff);
+    } else {
+      // byte offsets computed in 32 bits: "scalar base + 32-bit lane offset" addressing
+      const unsigned off = ((unsigned)c[r] * (unsigned)a.ldx + (unsigned)coloff) * 4u;
+      xv[r] = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.x) + off);
+      if (INCAGG) {
+        const unsigned moff = ((unsigned)c[r] * (unsigned)a.ldin + (unsigned)coloff) * 4u;
+        mv[r] = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.m_in) + moff);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < N; r++) acc += w[r] * (INCAGG ? xv[r] - mv[r] : xv[r]);
+}
+
+// acc += contributions of the window whose indices sit in (my_c, my_w); cnt = real edges
+// in it (wave-uniform).  Short rows only pay for the rounds they fill: 1, 2, 4 or 8.
+template <bool INCAGG, bool WIDE>
+__device__ __forceinline__ void gather_window(const SpmmArgs &a, int my_c, float my_w, int cnt,
+                                              int coloff, f4 &acc) {
+  if (cnt > 32) {
+    if constexpr (INCAGG) {  // two operands per edge: 4 rounds = 8 gathers in flight
+      gather_rounds<INCAGG, WIDE, 0, 4>(a, my_c, my_w, coloff, acc);
+      gather_rounds<INCAGG, WIDE, 4, 4>(a, my_c, my_w, coloff, acc);
+    } else {
+      gather_rounds<INCAGG, WIDE, 0, 8>(a, my_c, my_w, coloff, acc);
+    }
+  } else if (cnt > 16) {
+    gather_rounds<INCAGG, WIDE, 0, 4>(a, my_c, my_w, coloff, acc);
+  } else if (cnt > 8) {
+    gather_rounds<INCAGG, WIDE, 0, 2>(a, my_c, my_w, coloff, acc);
+  } else {
+    gather_rounds<INCAGG, WIDE, 0, 1>(a, my_c, my_w, coloff, acc);
+  }
+}
+
+__device__ __forceinline__ f4 sum_lane_groups(f4 acc) {
+  acc += shfl_xor4(acc, 8);
+  acc += shfl_xor4(acc, 16);
+  acc += shfl_xor4(acc, 32);
+  return acc;
+}
+
+template <bool INCAGG>
+__device__ __forceinline__ void sliced_store(const SpmmArgs &a, int row, f4 acc, float s, int g,
+                                             bool live, int coloff) {
+  if (g == 0 && live) {
+    f4 out = acc * s;
+    if (INCAGG) out += a.scale * ldv<4>(a.m_ag + (size_t)row * a.ldag + coloff);
+    if (a.add) out += a.add_scale * ldv<4>(a.add + (size_t)row * a.ldadd + coloff);
+    stv<4>(a.y + (size_t)row * a.ldy + coloff, out);
+  }
+}
+
+// Row pointers of the wave's rows live in lanes 0..n (lane i: rowptr[r0 + i]).
+__device__ __forceinline__ int row_start(int my_rp, int i) { return __builtin_amdgcn_readlane(my_rp, i); }
+
+template <bool INCAGG, bool WIDE>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_sliced_kernel(const SpmmArgs a,
+                                                                            int n_slices,
+                                                                            int rows_per_wave) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 3, t = lane & 7;
+  const int slice = blockIdx.x % n_slices;
+  const int r0 = ((blockIdx.x / n_slices) * kWavesPerBlock + wave) * rows_per_wave;
+  if (r0 >= a.n_rows) return;
+  const int nr = min(rows_per_wave, a.n_rows - r0);
+  const int col0 = slice * kSliceFloats + t * 4;
+  const bool live = col0 < a.width;
+  const int coloff = live ? col0 : 0;
+  const int my_rp = lane <= nr ? a.rowptr[r0 + lane] : 0;
+
+  // A wave walks its rows window by window (64 edges each) and always has the NEXT
+  // window's indices in flight while it gathers the current one -- also across the end
+  // of a row, which is what hides the rowptr -> indices -> gather dependency chain of
+  // the (many) short rows.  Rows without work for this loop (no edges, or so long that
+  // they are handed to the slice queue) are finished on the spot when the walk skips them.
+  auto finish_skipped = [&](int i) {
+    const int rs = row_start(my_rp, i), re = row_start(my_rp, i + 1);
+    const int deg = a.n_cols > 0 ? re - rs : 0;
+    if (deg > a.hub_threshold && slice == 0) {  // one wave per row enqueues its slices
+      const int ns = (deg + a.hub_slice - 1) / a.hub_slice;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.q_count, ns);
+      base = rfl(base);
+      if (base + ns <= a.q_cap) {
+        for (int k = lane; k < ns; k += kWave) a.queue[base + k] = make_int2(r0 + i, k);
+      } else {
+        for (int k = lane; k < ns && base + k < a.q_cap; k += kWave)
+          a.queue[base + k] = make_int2(-1, 0);
+        if (lane == 0) *a.err = 1;  // > 2^20 slices in one call: result incomplete, reported
+      }
+    }
+    sliced_store<INCAGG>(a, r0 + i, f4(0.f), 0.f, g, live, coloff);  // base value only
+  };
+  auto has_work = [&](int i) {
+    const int deg = row_start(my_rp, i + 1) - row_start(my_rp, i);
+    return a.n_cols > 0 && deg > 0 && deg <= a.hub_threshold;
+  };
+  // first row with work
+  int i = 0;
+  while (i < nr && !has_work(i)) finish_skipped(i++);
+  if (i >= nr) return;
+  int e0 = row_start(my_rp, i);
+  int my_c, next_c = 0;
+  float my_w, next_w = 0.f;
+  load_window(a, e0, row_start(my_rp, i + 1), lane, my_c, my_w);
+  f4 acc = f4(0.f);
+  while (i < nr) {
+    const int rs = row_start(my_rp, i), re = row_start(my_rp, i + 1);
+    // where the walk goes next
+    int ni = i, ne0 = e0 + kWave;
+    if (ne0 >= re) {
+      ni = i + 1;
+      while (ni < nr && !has_work(ni)) finish_skipped(ni++);
+      ne0 = ni < nr ? row_start(my_rp, ni) : 0;
+    }
+    if (ni < nr) load_window(a, ne0, row_start(my_rp, ni + 1), lane, next_c, next_w);
+    gather_window<INCAGG, WIDE>(a, my_c, my_w, min(kWave, re - e0), coloff, acc);
+    if (ni != i) {  // row i is complete
+      const float s = a.scale * (a.mean ? 1.0f / (float)(re - rs) : 1.0f);
+      sliced_store<INCAGG>(a, r0 + i, sum_lane_groups(acc), s, g, live, coloff);
+      acc = f4(0.f);
+    }
+    my_c = next_c;
+    my_w = next_w;
+    i = ni;
+    e0 = ne0;
+  }
+}
+
+template <bool INCAGG, bool WIDE>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_sliced_hub_kernel(const SpmmArgs a,
+                                                                                int n_slices) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int t = lane & 7;
+  const int n = min(rfl(*a.q_count), a.q_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.q_count_next = 0;  // for the next call
+  const int slice = blockIdx.x % n_slices;
+  const int col0 = slice * kSliceFloats + t * 4;
+  const bool live = col0 < a.width;
+  const int coloff = live ? col0 : 0;
+  const int stride = (gridDim.x / n_slices) * kWavesPerBlock;
+  for (int sidx = (blockIdx.x / n_slices) * kWavesPerBlock + wave; sidx < n; sidx += stride) {
+    const int2 ent = a.queue[sidx];
+    const int row = rfl(ent.x);
+    if (row < 0) continue;
+    const int k = rfl(ent.y);
+    const int rs0 = rfl(a.rowptr[row]);
+    const int re0 = rfl(a.rowptr[row + 1]);
+    const int rs = rs0 + k * a.hub_slice;
+    const int re = min(re0, rs + a.hub_slice);
+    f4 acc = f4(0.f);
+    int my_c, next_c = 0;
+    float my_w, next_w = 0.f;
+    load_window(a, rs, re, lane, my_c, my_w);
+    for (int e0 = rs; e0 < re; e0 += kWave) {
+      if (e0 + kWave < re) load_window(a, e0 + kWave, re, lane, next_c, next_w);
+      gather_window<INCAGG, WIDE>(a, my_c, my_w, min(kWave, re - e0), coloff, acc);
+      my_c = next_c;
+      my_w = next_w;
+    }
+    acc = sum_lane_groups(acc);
+    const float s = a.scale * (a.mean ? 1.0f / (float)max(re0 - rs0, 1) : 1.0f);
+    // lanes 0..31 each add one float: one 128-byte segment per atomic wave-instruction
+    const int src = lane >> 2, sel = lane & 3;
+    const float v0 = __shfl(acc.x, src), v1 = __shfl(acc.y, src);
+    const float v2 = __shfl(acc.z, src), v3 = __shfl(acc.w, src);
+    const float v = sel == 0 ? v0 : sel == 1 ? v1 : sel == 2 ? v2 : v3;
+    const int c = slice * kSliceFloats + lane;
+    if (lane < kSliceFloats && c < a.width) atomicAdd(a.y + (size_t)row * a.ldy + c, v * s);
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void rows_sub_kernel(const float *a, long long lda,
                                                       const float *b, long long ldb,
@@ -323,11 +583,28 @@ static int env_int(const char *name, int fallback) {
   return v && *v ? atoi(v) : fallback;
 }
 
+// Launch tuning.  Defaults are the measured optima (see launch_spmm / launch_sliced);
+// INCAGG_* environment variables seed them, incagg_set_tuning() changes them at run time
+// (used by the A/B benchmarks and by the tests to force either kernel variant).
+struct Tuning {
+  int spmm_sliced = env_int("INCAGG_SPMM_SLICED", -1);          // -1 by shape, 0 rows, 1 sliced
+  int hub_threshold = env_int("INCAGG_HUB_THRESHOLD", kHubThreshold);
+  int hub_slice = env_int("INCAGG_HUB_SLICE", kHubSlice);
+  int hub_blocks = env_int("INCAGG_HUB_BLOCKS", 2048);
+  int sliced_hub_threshold = env_int("INCAGG_SLICED_HUB_THRESHOLD", 256);
+  int sliced_hub_slice = env_int("INCAGG_SLICED_HUB_SLICE", 128);
+  int sliced_rows_per_wave = env_int("INCAGG_SLICED_ROWS_PER_WAVE", 4);
+};
+static Tuning &tuning() {
+  static Tuning t;
+  return t;
+}
+
 template <int VEC, int CH, bool INCAGG>
 static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
-  static const int hub_threshold = std::max(1, env_int("INCAGG_HUB_THRESHOLD", kHubThreshold));
-  static const int hub_slice = std::max(1, env_int("INCAGG_HUB_SLICE", kHubSlice));
-  static const int hub_blocks = std::max(1, env_int("INCAGG_HUB_BLOCKS", 2048));
+  const int hub_threshold = std::max(1, tuning().hub_threshold);
+  const int hub_slice = std::max(1, tuning().hub_slice);
+  const int hub_blocks = std::max(1, tuning().hub_blocks);
   a.hub_slice = hub_slice;
   const bool may_have_hubs = max_row_nnz < 0 || max_row_nnz > hub_threshold;
   HubQueue *q = nullptr;
@@ -359,8 +636,72 @@ static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
 }
 
 template <bool INCAGG>
-static int dispatch_spmm(SpmmArgs &a, bool vec4, long long max_row_nnz, hipStream_t stream) {
+static int launch_sliced(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
+  // a wave covers up to 64 edges per memory round trip here, so rows are cut later and into
+  // longer slices than in the whole-row kernel (measured on an ogbn-products-sized batch:
+  // threshold/slice 1024/512 -> 93.7 us, 512/256 -> 89.8 us, 256/128 -> 88.6 us per launch
+  // pair at 4 rows per wave; 16 rows per wave -> 97 us)
+  const int hub_threshold = std::max(1, tuning().sliced_hub_threshold);
+  const int hub_slice = std::max(64, tuning().sliced_hub_slice);  // 2^20 slices cover 134M hub edges
+  const int hub_blocks = std::max(1, tuning().hub_blocks);
+  const int n_slices = (a.width + kSliceFloats - 1) / kSliceFloats;
+  a.hub_slice = hub_slice;
+  const bool may_have_hubs = max_row_nnz < 0 || max_row_nnz > hub_threshold;
+  HubQueue *q = nullptr;
+  if (may_have_hubs) {
+    int rc = hub_queue_for(stream, &q);
+    if (rc) return rc;
+    a.hub_threshold = hub_threshold;
+    a.queue = q->entries;
+    a.q_count = q->counters + q->parity;
+    a.q_count_next = q->counters + (q->parity ^ 1);
+    a.q_cap = kQueueCap;
+  } else {
+    a.hub_threshold = INT_MAX;
+  }
+  const int rows_per_wave = std::min(63, std::max(1, tuning().sliced_rows_per_wave));
+  const long long rows_per_block = (long long)kWavesPerBlock * rows_per_wave;
+  const long long row_groups = (a.n_rows + rows_per_block - 1) / rows_per_block;
+  if (row_groups * n_slices > INT_MAX) return fail(INCAGG_E_INVALID, "grid too large");
+  // 32-bit byte offsets on a scalar base cover a single source matrix of < 4 GiB
+  const bool wide = a.x2 != nullptr || (long long)a.n_cols * a.ldx * 4 >= (1ll << 32) ||
+                    (INCAGG && (long long)a.n_cols * a.ldin * 4 >= (1ll << 32));
+  const dim3 grid((unsigned)(row_groups * n_slices)), block(kWave * kWavesPerBlock);
+  if (wide)
+    hipLaunchKernelGGL((spmm_sliced_kernel<INCAGG, true>), grid, block, 0, stream, a, n_slices,
+                       rows_per_wave);
+  else
+    hipLaunchKernelGGL((spmm_sliced_kernel<INCAGG, false>), grid, block, 0, stream, a, n_slices,
+                       rows_per_wave);
+  INCAGG_HIP_TRY(hipGetLastError());
+  if (may_have_hubs) {
+    const dim3 hub_grid(std::max(1, hub_blocks / n_slices) * n_slices);
+    if (wide)
+      hipLaunchKernelGGL((spmm_sliced_hub_kernel<INCAGG, true>), hub_grid, block, 0, stream, a,
+                         n_slices);
+    else
+      hipLaunchKernelGGL((spmm_sliced_hub_kernel<INCAGG, false>), hub_grid, block, 0, stream, a,
+                         n_slices);
+    INCAGG_HIP_TRY(hipGetLastError());
+    q->parity ^= 1;
+  }
+  return INCAGG_OK;
+}
+
+template <bool INCAGG>
+static int dispatch_spmm(SpmmArgs &a, bool vec4, long long nnz, long long max_row_nnz,
+                         hipStream_t stream) {
   const int w = a.width;
+  // INCAGG_SPMM_SLICED: 0 = whole rows per wave, 1 = feature-sliced (one 128-byte slice per
+  // XCD) wherever possible, default = by shape.  Measured on MI355X (ogbn-products-sized
+  // batch, width 256): sliced wins where rows are long enough to amortise visiting every row
+  // once per slice and the source is one matrix (forward over [B, M]: 89 vs 98 us; two-operand
+  // incremental aggregate: step time -6 %); it loses on very short rows (transposed [M, B]
+  // with 7 edges per row: 270 vs 171 us) and with a split source (101 vs 93 us).
+  const int mode = tuning().spmm_sliced;
+  const bool by_shape = w >= 2 * kSliceFloats && a.x2 == nullptr && nnz >= 16ll * a.n_rows;
+  const bool sliced = vec4 && (mode == 1 || (mode == -1 && by_shape));
+  if (sliced) return launch_sliced<INCAGG>(a, max_row_nnz, stream);
   if (vec4) {
     if (w <= 256) return launch_spmm<4, 1, INCAGG>(a, max_row_nnz, stream);
     if (w <= 512) return launch_spmm<4, 2, INCAGG>(a, max_row_nnz, stream);
@@ -403,8 +744,10 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
                                    int64_t ld_halo, int64_t n_split, int64_t n_rows,
                                    int64_t n_cols, int64_t width, int reduce, float scale,
                                    const float *add, int64_t ldadd, float add_scale,
-                                   int64_t max_row_nnz, float *y, int64_t ldy, void *stream) {
+                                   int64_t nnz, int64_t max_row_nnz, float *y, int64_t ldy,
+                                   void *stream) {
   int rc = check_common(rowptr, col, x, ldx, n_rows, n_cols, width, reduce, add, ldadd, y, ldy);
+  INCAGG_REQUIRE(nnz >= 0 && nnz < INT_MAX, "nnz %lld out of range", (long long)nnz);
   if (rc) return rc;
   if (n_rows == 0 || width == 0) return INCAGG_OK;
   if (!x_halo) n_split = n_cols;
@@ -423,7 +766,7 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
   if (rc) return rc;
   const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(x_halo, ld_halo) &&
                     rows_vec4(add, ldadd) && rows_vec4(y, ldy);
-  return dispatch_spmm<false>(a, vec4, max_row_nnz, static_cast<hipStream_t>(stream));
+  return dispatch_spmm<false>(a, vec4, nnz, max_row_nnz, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col,
@@ -431,9 +774,10 @@ extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *
                                           const float *m_in, int64_t ldin, const float *m_ag,
                                           int64_t ldag, int64_t n_rows, int64_t width, int reduce,
                                           float scale, const float *add, int64_t ldadd,
-                                          float add_scale, int64_t max_row_nnz, float *h,
-                                          int64_t ldh, void *stream) {
+                                          float add_scale, int64_t nnz, int64_t max_row_nnz,
+                                          float *h, int64_t ldh, void *stream) {
   int rc = check_common(rowptr, col, x, ldx, n_rows, n_rows, width, reduce, add, ldadd, h, ldh);
+  INCAGG_REQUIRE(nnz >= 0 && nnz < INT_MAX, "nnz %lld out of range", (long long)nnz);
   if (rc) return rc;
   if (n_rows == 0 || width == 0) return INCAGG_OK;
   INCAGG_REQUIRE(m_in && m_ag, "null m_in or m_ag");
@@ -450,7 +794,22 @@ extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *
   if (rc) return rc;
   const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(m_in, ldin) &&
                     rows_vec4(m_ag, ldag) && rows_vec4(add, ldadd) && rows_vec4(h, ldh);
-  return dispatch_spmm<true>(a, vec4, max_row_nnz, static_cast<hipStream_t>(stream));
+  return dispatch_spmm<true>(a, vec4, nnz, max_row_nnz, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int incagg_set_tuning(const char *key, int value) {
+  INCAGG_REQUIRE(key != nullptr, "null key");
+  Tuning &t = tuning();
+  const std::string k(key);
+  if (k == "spmm_sliced") t.spmm_sliced = value;
+  else if (k == "hub_threshold") t.hub_threshold = value;
+  else if (k == "hub_slice") t.hub_slice = value;
+  else if (k == "hub_blocks") t.hub_blocks = value;
+  else if (k == "sliced_hub_threshold") t.sliced_hub_threshold = value;
+  else if (k == "sliced_hub_slice") t.sliced_hub_slice = value;
+  else if (k == "sliced_rows_per_wave") t.sliced_rows_per_wave = value;
+  else return fail(INCAGG_E_INVALID, "unknown tuning key '%s'", key);
+  return INCAGG_OK;
 }
 
 extern "C" int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, int64_t ldb,

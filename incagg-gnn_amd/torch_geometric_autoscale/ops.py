@@ -92,8 +92,19 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(x_halo),
             0 if x_halo is None else _ld(x_halo), n_split, n_rows, n_cols, width,
             REDUCE[reduce], float(scale), _ptr(add), 0 if add is None else _ld(add),
-            float(add_scale), int(max_row_nnz), _ptr(out), _ld(out), _stream_of(dev)))
+            float(add_scale), _window_nnz(rowptr32, col32), int(max_row_nnz), _ptr(out), _ld(out),
+            _stream_of(dev)))
     return out
+
+
+def _window_nnz(rowptr32: Tensor, col32: Tensor) -> int:
+    """Edge count of the rows addressed by ``rowptr32`` without reading device memory: the
+    full edge array, scaled by the share of rows when ``rowptr32`` is a window of a longer
+    row-pointer array (the transposed CSR restricted to in-batch columns)."""
+    base = rowptr32._base
+    if base is None or base.numel() <= 1:
+        return int(col32.numel())
+    return int(col32.numel() * (rowptr32.numel() - 1) / (base.numel() - 1))
 
 
 def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor,
@@ -121,8 +132,8 @@ def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: T
         check(lib().incagg_spmm_csr_incagg_f32(
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(m_in), _ld(m_in),
             _ptr(m_ag), _ld(m_ag), n_rows, width, REDUCE[reduce], float(scale), _ptr(add),
-            0 if add is None else _ld(add), float(add_scale), int(max_row_nnz), _ptr(out), _ld(out),
-            _stream_of(dev)))
+            0 if add is None else _ld(add), float(add_scale), int(col32.numel()),
+            int(max_row_nnz), _ptr(out), _ld(out), _stream_of(dev)))
     return out
 
 

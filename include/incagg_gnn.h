@@ -72,23 +72,27 @@ int incagg_check_device_errors(void);
  *     "fresh in-batch rows + pulled out-of-batch History rows" without materialising
  *     their concatenation (the torch.cat of models/base.py:426,451).
  *   reduce: INCAGG_REDUCE_SUM | INCAGG_REDUCE_MEAN (divide by max(row length, 1))
+ *   nnz: number of edges (= rowptr[n_rows] - rowptr[0]; the host cannot read it from the
+ *     device array), used to pick the kernel variant by average row length.
  *   max_row_nnz: length of the longest row if the caller knows it, else -1.
  *   y[n_rows, width] ld = ldy; must not alias x.
  *   width <= 1024 when every pointer is 16-byte aligned and every ld a multiple
  *   of 4, else width <= 256.
  *
- * Rows longer than 128 edges are cut into 64-edge slices that are summed onto
- * the row with fp32 atomics by a second launch (skipped when max_row_nnz says
- * there is no such row), so such rows are reproducible only up to fp32 rounding
- * order.  The slice queue is device memory the library allocates once per
+ * Two kernel variants, chosen by shape: whole rows per wave, or (width >= 64, one source
+ * matrix, >= 16 edges per row on average) 128-byte feature slices pinned to one XCD each so
+ * that every source byte has a single home L2.  Rows longer than 128 (256) edges are cut
+ * into 64 (128)-edge slices that are summed onto the row with fp32 atomics by a second
+ * launch (skipped when max_row_nnz says there is no such row), so such rows are
+ * reproducible only up to fp32 rounding order.  The slice queue is device memory the library allocates once per
  * (device, stream) on the first call that may need it.
  */
 int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                         const float *x, int64_t ldx, const float *x_halo, int64_t ld_halo,
                         int64_t n_split, int64_t n_rows, int64_t n_cols, int64_t width,
                         int reduce, float scale, const float *add, int64_t ldadd,
-                        float add_scale, int64_t max_row_nnz, float *y, int64_t ldy,
-                        void *stream);
+                        float add_scale, int64_t nnz, int64_t max_row_nnz, float *y,
+                        int64_t ldy, void *stream);
 
 /*
  * Fused incremental aggregate (the fork's contribution):
@@ -103,8 +107,16 @@ int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col, const 
                                const float *x, int64_t ldx, const float *m_in,
                                int64_t ldin, const float *m_ag, int64_t ldag,
                                int64_t n_rows, int64_t width, int reduce, float scale,
-                               const float *add, int64_t ldadd, float add_scale,
+                               const float *add, int64_t ldadd, float add_scale, int64_t nnz,
                                int64_t max_row_nnz, float *h, int64_t ldh, void *stream);
+
+/*
+ * Launch tuning of the aggregation (no counterpart in the reference; for benchmarks and
+ * tests).  Keys: "spmm_sliced" (-1 choose by shape, 0 whole rows per wave, 1 feature slices),
+ * "hub_threshold", "hub_slice", "hub_blocks", "sliced_hub_threshold", "sliced_hub_slice",
+ * "sliced_rows_per_wave".  Not thread-safe against concurrent aggregation calls.
+ */
+int incagg_set_tuning(const char *key, int value);
 
 /* d[i,:] = a[i,:] - b[i,:] over [n_rows, width]; the unfused first step of the
  * incremental aggregate (`x - M_in`, models/gcn2.py:255). */

@@ -16,7 +16,8 @@ rp, c, v = adj.device_csr()
 B, M, E, F = adj.size(0), adj.size(1), adj.nnz(), int(os.environ.get("F", "256"))
 deg = (rp[1:] - rp[:-1]).cpu()
 print(f"B={B} M={M} E={E} F={F} maxdeg={int(deg.max())} rows>128: {(deg>128).sum().item()} edges in rows>128: {deg[deg>128].sum().item()}")
-x = torch.randn(M, F, device=dev)
+PAD = int(os.environ.get("PAD", "0"))
+x = torch.randn(M, F + PAD, device=dev)[:, :F]
 def run(n=30, **kw):
     for _ in range(3): ops.spmm_csr(rp, c, v, x, M, "sum", max_row_nnz=adj.max_row_nnz(), **kw)
     torch.cuda.synchronize()

@@ -27,6 +27,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=["rows", "sliced", "auto"])
+def variant(request):
+    """Forces the whole-row or the feature-sliced aggregation kernel (or the shape heuristic)."""
+    from torch_geometric_autoscale import _lib
+    _lib.set_tuning("spmm_sliced", {"rows": 0, "sliced": 1, "auto": -1}[request.param])
+    yield request.param
+    _lib.set_tuning("spmm_sliced", -1)
+
+
 def _dev_csr(rowptr, col, val, dev):
     return (torch.from_numpy(rowptr.astype(np.int32)).to(dev),
             torch.from_numpy(col.astype(np.int32)).to(dev),
@@ -46,7 +55,7 @@ WIDTHS = [256, 128, 100, 64, 41, 47, 4, 1, 3, 260, 512, 1024]
 
 @pytest.mark.parametrize("width", WIDTHS)
 @pytest.mark.parametrize("reduce", ["sum", "mean"])
-def test_spmm_matches_oracle(ops, dev, width, reduce):
+def test_spmm_matches_oracle(ops, dev, width, reduce, variant):
     from torch_geometric_autoscale import _lib
     rng = np.random.default_rng(width * 7 + (reduce == "mean"))
     n_rows, n_cols = 300, 700
@@ -63,7 +72,7 @@ def test_spmm_matches_oracle(ops, dev, width, reduce):
     _lib.check_device_errors()
 
 
-def test_spmm_epilogue_and_strides(ops, dev):
+def test_spmm_epilogue_and_strides(ops, dev, variant):
     rng = np.random.default_rng(3)
     n_rows, n_cols, width = 257, 400, 256
     rowptr, col, val = random_csr(rng, n_rows, n_cols, 30)
@@ -77,7 +86,7 @@ def test_spmm_epilogue_and_strides(ops, dev):
     _check(y, y64)
 
 
-def test_spmm_hub_rows_sliced(ops, dev):
+def test_spmm_hub_rows_sliced(ops, dev, variant):
     """Rows far beyond the slicing threshold, incl. one that covers every column twice over."""
     rng = np.random.default_rng(11)
     n_rows, n_cols, width = 64, 6000, 256
@@ -118,7 +127,7 @@ def test_spmm_bad_column_is_skipped_and_reported(ops, dev):
 
 @pytest.mark.parametrize("width", [256, 128, 41, 512])
 @pytest.mark.parametrize("reduce", ["sum", "mean"])
-def test_incagg_matches_oracle(ops, dev, width, reduce):
+def test_incagg_matches_oracle(ops, dev, width, reduce, variant):
     rng = np.random.default_rng(width + 1000)
     b = 500
     rowptr, col, val = random_csr(rng, b, b, 12, hubs={3: 500, 4: 499}, empty_rows=(9,),
@@ -225,7 +234,7 @@ def test_gather_from_pinned_host_table(ops, dev):
     assert torch.equal(emb[n_id], x)
 
 
-def test_full_size_properties(ops, dev):
+def test_full_size_properties(ops, dev, variant):
     """ogbn-products-like partition batch (B = 16k rows, ~0.84M edges, F = 256): properties
     that need no CPU oracle -- linearity in x, A @ 1 = row sums, mean of a constant."""
     rng = np.random.default_rng(2026)
