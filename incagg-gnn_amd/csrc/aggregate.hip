@@ -78,6 +78,7 @@ struct SpmmArgs {
   int *q_count_next;
   int q_cap;
   int *err;
+  const int *row_order;  // grouped kernel: processing order of the rows (nullptr = identity)
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -532,6 +533,117 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_sliced_hub_kernel(
   }
 }
 
+// ---------------------------------------------------------------- grouped feature-sliced variant
+// Same slice-per-XCD placement, but every group of 8 lanes owns its own destination row: a
+// wave handles 8 rows x one 128-byte slice, each group walks its row's edges 8 at a time
+// (one coalesced 32-byte index load per group, broadcast inside the group with ds_swizzle)
+// and keeps its own accumulator, so there is no cross-lane reduction and no per-row walk
+// logic -- about 1.5x fewer instructions per gathered byte than one row per wave.  The trip
+// count of a wave is set by its longest row; `row_order` (optional) lists the rows so that 8
+// consecutive entries have similar degrees (built once per batch on the host side).
+__device__ __forceinline__ int group_max8(int v) {  // max over the 8 lane groups of a wave
+  v = max(v, __shfl_xor(v, 8));
+  v = max(v, __shfl_xor(v, 16));
+  v = max(v, __shfl_xor(v, 32));
+  return v;
+}
+
+template <bool INCAGG, bool WIDE>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_grouped_kernel(
+    const SpmmArgs a, int n_slices) {
+  const int *__restrict__ row_order = a.row_order;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 3, t = lane & 7;
+  const int slice = blockIdx.x % n_slices;
+  const int p = ((blockIdx.x / n_slices) * kWavesPerBlock + wave) * 8 + g;
+  const int col0 = slice * kSliceFloats + t * 4;
+  const bool live = col0 < a.width;
+  const int coloff = live ? col0 : 0;
+  const bool valid = p < a.n_rows;
+  int row = 0, rs = 0, re = 0;
+  if (valid) {
+    row = row_order ? row_order[p] : p;
+    if ((unsigned)row >= (unsigned)a.n_rows) {  // bad permutation entry: reported, not followed
+      *a.err = 1;
+      row = p;
+    }
+    rs = a.rowptr[row];
+    re = a.rowptr[row + 1];
+  }
+  const int full_deg = a.n_cols > 0 ? re - rs : 0;
+  int deg = full_deg;
+  if (deg > a.hub_threshold) {
+    if (slice == 0) {  // one lane group per row enqueues its slices
+      const int ns = (deg + a.hub_slice - 1) / a.hub_slice;
+      int base = 0;
+      if (t == 0) base = atomicAdd(a.q_count, ns);
+      base = group_bcast<0>(base);
+      if (base + ns <= a.q_cap) {
+        for (int k = t; k < ns; k += 8) a.queue[base + k] = make_int2(row, k);
+      } else {
+        for (int k = t; k < ns && base + k < a.q_cap; k += 8) a.queue[base + k] = make_int2(-1, 0);
+        *a.err = 1;  // > 2^20 slices in one call: result incomplete, reported
+      }
+    }
+    deg = 0;  // only the base value is stored here
+  }
+  re = rs + deg;
+  const int maxdeg = rfl(group_max8(deg));
+
+  // Lane t of a group holds edge e + t; lanes past the row's end re-read its last edge
+  // with weight 0, so the gather rounds need no per-lane guards.
+  auto load_idx = [&](int e0, int &c, float &w) {
+    if (e0 < re) {
+      const int slot = e0 + t;
+      const int e = min(slot, re - 1);
+      c = a.col[e];
+      w = a.val ? a.val[e] : 1.0f;
+      if (slot >= re) w = 0.f;
+      if ((unsigned)c >= (unsigned)a.n_cols) {  // never fault on a bad id
+        *a.err = 1;
+        c = 0;
+        w = 0.f;
+      }
+    }
+  };
+  f4 acc = f4(0.f);
+  int e = rs;
+  int my_c = 0, next_c = 0;
+  float my_w = 0.f, next_w = 0.f;
+  load_idx(e, my_c, my_w);
+  for (int done = 0; done < maxdeg; done += 8) {
+    if (done + 8 < maxdeg) load_idx(e + 8, next_c, next_w);
+    const int rem = maxdeg - done;  // wave-uniform: rounds that some group still needs
+    if (e < re) {
+      if (rem > 4) {
+        if constexpr (INCAGG) {  // two operands per edge: 4 rounds = 8 gathers in flight
+          gather_rounds<INCAGG, WIDE, 0, 4>(a, my_c, my_w, coloff, acc);
+          gather_rounds<INCAGG, WIDE, 4, 4>(a, my_c, my_w, coloff, acc);
+        } else {
+          gather_rounds<INCAGG, WIDE, 0, 8>(a, my_c, my_w, coloff, acc);
+        }
+      } else if (rem > 2) {
+        gather_rounds<INCAGG, WIDE, 0, 4>(a, my_c, my_w, coloff, acc);
+      } else if (rem > 1) {
+        gather_rounds<INCAGG, WIDE, 0, 2>(a, my_c, my_w, coloff, acc);
+      } else {
+        gather_rounds<INCAGG, WIDE, 0, 1>(a, my_c, my_w, coloff, acc);
+      }
+    }
+    my_c = next_c;
+    my_w = next_w;
+    e += 8;
+  }
+  if (valid && live) {
+    const float s = a.scale * (a.mean ? 1.0f / (float)max(full_deg, 1) : 1.0f);
+    f4 out = acc * s;
+    if (INCAGG) out += a.scale * ldv<4>(a.m_ag + (size_t)row * a.ldag + coloff);
+    if (a.add) out += a.add_scale * ldv<4>(a.add + (size_t)row * a.ldadd + coloff);
+    stv<4>(a.y + (size_t)row * a.ldy + coloff, out);
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void rows_sub_kernel(const float *a, long long lda,
                                                       const float *b, long long ldb,
@@ -594,6 +706,8 @@ struct Tuning {
   int sliced_hub_threshold = env_int("INCAGG_SLICED_HUB_THRESHOLD", 256);
   int sliced_hub_slice = env_int("INCAGG_SLICED_HUB_SLICE", 128);
   int sliced_rows_per_wave = env_int("INCAGG_SLICED_ROWS_PER_WAVE", 4);
+  int grouped_hub_threshold = env_int("INCAGG_GROUPED_HUB_THRESHOLD", 128);
+  int grouped_hub_slice = env_int("INCAGG_GROUPED_HUB_SLICE", 128);
 };
 static Tuning &tuning() {
   static Tuning t;
@@ -636,13 +750,17 @@ static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
 }
 
 template <bool INCAGG>
-static int launch_sliced(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
+static int launch_sliced(SpmmArgs &a, long long max_row_nnz, bool grouped, hipStream_t stream) {
   // a wave covers up to 64 edges per memory round trip here, so rows are cut later and into
   // longer slices than in the whole-row kernel (measured on an ogbn-products-sized batch:
   // threshold/slice 1024/512 -> 93.7 us, 512/256 -> 89.8 us, 256/128 -> 88.6 us per launch
   // pair at 4 rows per wave; 16 rows per wave -> 97 us)
-  const int hub_threshold = std::max(1, tuning().sliced_hub_threshold);
-  const int hub_slice = std::max(64, tuning().sliced_hub_slice);  // 2^20 slices cover 134M hub edges
+  // (8 rows per wave: a lane group covers only 8 edges per round trip, so rows are cut
+  // earlier; 64..128 / 128 are equally good, 32 / 64 and 512 / 128 lose 20-30 %)
+  const int hub_threshold = std::max(1, grouped ? tuning().grouped_hub_threshold
+                                                : tuning().sliced_hub_threshold);
+  // 2^20 slices of >= 64 edges cover 67M hub edges per call
+  const int hub_slice = std::max(64, grouped ? tuning().grouped_hub_slice : tuning().sliced_hub_slice);
   const int hub_blocks = std::max(1, tuning().hub_blocks);
   const int n_slices = (a.width + kSliceFloats - 1) / kSliceFloats;
   a.hub_slice = hub_slice;
@@ -659,7 +777,7 @@ static int launch_sliced(SpmmArgs &a, long long max_row_nnz, hipStream_t stream)
   } else {
     a.hub_threshold = INT_MAX;
   }
-  const int rows_per_wave = std::min(63, std::max(1, tuning().sliced_rows_per_wave));
+  const int rows_per_wave = grouped ? 8 : std::min(63, std::max(1, tuning().sliced_rows_per_wave));
   const long long rows_per_block = (long long)kWavesPerBlock * rows_per_wave;
   const long long row_groups = (a.n_rows + rows_per_block - 1) / rows_per_block;
   if (row_groups * n_slices > INT_MAX) return fail(INCAGG_E_INVALID, "grid too large");
@@ -667,7 +785,11 @@ static int launch_sliced(SpmmArgs &a, long long max_row_nnz, hipStream_t stream)
   const bool wide = a.x2 != nullptr || (long long)a.n_cols * a.ldx * 4 >= (1ll << 32) ||
                     (INCAGG && (long long)a.n_cols * a.ldin * 4 >= (1ll << 32));
   const dim3 grid((unsigned)(row_groups * n_slices)), block(kWave * kWavesPerBlock);
-  if (wide)
+  if (grouped && wide)
+    hipLaunchKernelGGL((spmm_grouped_kernel<INCAGG, true>), grid, block, 0, stream, a, n_slices);
+  else if (grouped)
+    hipLaunchKernelGGL((spmm_grouped_kernel<INCAGG, false>), grid, block, 0, stream, a, n_slices);
+  else if (wide)
     hipLaunchKernelGGL((spmm_sliced_kernel<INCAGG, true>), grid, block, 0, stream, a, n_slices,
                        rows_per_wave);
   else
@@ -692,16 +814,18 @@ template <bool INCAGG>
 static int dispatch_spmm(SpmmArgs &a, bool vec4, long long nnz, long long max_row_nnz,
                          hipStream_t stream) {
   const int w = a.width;
-  // INCAGG_SPMM_SLICED: 0 = whole rows per wave, 1 = feature-sliced (one 128-byte slice per
-  // XCD) wherever possible, default = by shape.  Measured on MI355X (ogbn-products-sized
-  // batch, width 256): sliced wins where rows are long enough to amortise visiting every row
-  // once per slice and the source is one matrix (forward over [B, M]: 89 vs 98 us; two-operand
-  // incremental aggregate: step time -6 %); it loses on very short rows (transposed [M, B]
-  // with 7 edges per row: 270 vs 171 us) and with a split source (101 vs 93 us).
+  // Variant ("spmm_sliced" tuning key): 0 = whole rows per wave, 1 = feature-sliced with one
+  // row per wave, 2 = feature-sliced with 8 rows per wave, -1 (default) = by shape.  Measured
+  // on MI355X, ogbn-products-sized batch at width 256, us per call (rows / sliced / grouped with
+  // a degree-sorted row_order): forward [B, M] 98 / 86 / 77; split source 97 / 93 / 90;
+  // transposed [M, B] with 7 edges per row 175 / 262 / 88; transposed [B, B] 67 / 65 / 55.
+  // Without a row_order the grouped kernel's lane groups idle behind the longest of their 8
+  // rows (forward 107 us), so it is only chosen when the caller supplies one.
   const int mode = tuning().spmm_sliced;
   const bool by_shape = w >= 2 * kSliceFloats && a.x2 == nullptr && nnz >= 16ll * a.n_rows;
+  const bool grouped = vec4 && (mode == 2 || (mode == -1 && a.row_order != nullptr));
   const bool sliced = vec4 && (mode == 1 || (mode == -1 && by_shape));
-  if (sliced) return launch_sliced<INCAGG>(a, max_row_nnz, stream);
+  if (grouped || sliced) return launch_sliced<INCAGG>(a, max_row_nnz, grouped, stream);
   if (vec4) {
     if (w <= 256) return launch_spmm<4, 1, INCAGG>(a, max_row_nnz, stream);
     if (w <= 512) return launch_spmm<4, 2, INCAGG>(a, max_row_nnz, stream);
@@ -744,8 +868,8 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
                                    int64_t ld_halo, int64_t n_split, int64_t n_rows,
                                    int64_t n_cols, int64_t width, int reduce, float scale,
                                    const float *add, int64_t ldadd, float add_scale,
-                                   int64_t nnz, int64_t max_row_nnz, float *y, int64_t ldy,
-                                   void *stream) {
+                                   int64_t nnz, int64_t max_row_nnz, const int32_t *row_order,
+                                   float *y, int64_t ldy, void *stream) {
   int rc = check_common(rowptr, col, x, ldx, n_rows, n_cols, width, reduce, add, ldadd, y, ldy);
   INCAGG_REQUIRE(nnz >= 0 && nnz < INT_MAX, "nnz %lld out of range", (long long)nnz);
   if (rc) return rc;
@@ -762,6 +886,7 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
   a.add = add; a.ldadd = ldadd; a.y = y; a.ldy = ldy;
   a.n_rows = (int)n_rows; a.n_cols = (int)n_cols; a.width = (int)width;
   a.mean = reduce == INCAGG_REDUCE_MEAN; a.scale = scale; a.add_scale = add_scale;
+  a.row_order = row_order;
   rc = error_flag_address(&a.err);
   if (rc) return rc;
   const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(x_halo, ld_halo) &&
@@ -775,7 +900,8 @@ extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *
                                           int64_t ldag, int64_t n_rows, int64_t width, int reduce,
                                           float scale, const float *add, int64_t ldadd,
                                           float add_scale, int64_t nnz, int64_t max_row_nnz,
-                                          float *h, int64_t ldh, void *stream) {
+                                          const int32_t *row_order, float *h, int64_t ldh,
+                                          void *stream) {
   int rc = check_common(rowptr, col, x, ldx, n_rows, n_rows, width, reduce, add, ldadd, h, ldh);
   INCAGG_REQUIRE(nnz >= 0 && nnz < INT_MAX, "nnz %lld out of range", (long long)nnz);
   if (rc) return rc;
@@ -790,6 +916,7 @@ extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *
   a.add = add; a.ldadd = ldadd; a.y = h; a.ldy = ldh;
   a.n_rows = (int)n_rows; a.n_cols = (int)n_rows; a.width = (int)width;
   a.mean = reduce == INCAGG_REDUCE_MEAN; a.scale = scale; a.add_scale = add_scale;
+  a.row_order = row_order;
   rc = error_flag_address(&a.err);
   if (rc) return rc;
   const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(m_in, ldin) &&
@@ -808,6 +935,8 @@ extern "C" int incagg_set_tuning(const char *key, int value) {
   else if (k == "sliced_hub_threshold") t.sliced_hub_threshold = value;
   else if (k == "sliced_hub_slice") t.sliced_hub_slice = value;
   else if (k == "sliced_rows_per_wave") t.sliced_rows_per_wave = value;
+  else if (k == "grouped_hub_threshold") t.grouped_hub_threshold = value;
+  else if (k == "grouped_hub_slice") t.grouped_hub_slice = value;
   else return fail(INCAGG_E_INVALID, "unknown tuning key '%s'", key);
   return INCAGG_OK;
 }

@@ -20,10 +20,10 @@ SIGNATURES = {
     "incagg_device_count": (_int, []),
     "incagg_check_device_errors": (_int, []),
     "incagg_spmm_csr_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64,
-                                   _int, _f32, _vp, _i64, _f32, _i64, _i64, _vp, _i64, _vp]),
+                                   _int, _f32, _vp, _i64, _f32, _i64, _i64, _vp, _vp, _i64, _vp]),
     "incagg_spmm_csr_incagg_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
-                                          _i64, _int, _f32, _vp, _i64, _f32, _i64, _i64, _vp, _i64,
-                                          _vp]),
+                                          _i64, _int, _f32, _vp, _i64, _f32, _i64, _i64, _vp, _vp,
+                                          _i64, _vp]),
     "incagg_set_tuning": (_int, [_c.c_char_p, _int]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),

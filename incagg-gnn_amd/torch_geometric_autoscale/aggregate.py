@@ -32,7 +32,7 @@ class _SpMM(torch.autograd.Function):
     def forward(ctx, x, x_halo, add, adj, reduce, scale, add_scale):
         rowptr, col, val = adj.device_csr()
         y = ops.spmm_csr(rowptr, col, val, x, adj.size(1), reduce, scale, add, add_scale,
-                         adj.max_row_nnz(), x_halo=x_halo)
+                         adj.max_row_nnz(), x_halo=x_halo, row_order=adj.row_order())
         ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
         ctx.x_rows = x.size(0)
         ctx.halo_rows = None if x_halo is None else x_halo.size(0)
@@ -66,7 +66,7 @@ class _IncAgg(torch.autograd.Function):
     def forward(ctx, x, add, m_in, m_ag, adj, reduce, scale, add_scale):
         rowptr, col, val = adj.device_csr()
         h = ops.spmm_csr_incagg(rowptr, col, val, x, m_in, m_ag, reduce, scale, add, add_scale,
-                                adj.max_row_nnz())
+                                adj.max_row_nnz(), row_order=adj.row_order())
         ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
         ctx.x_rows = x.size(0)
         ctx.has_add = add is not None
@@ -92,7 +92,7 @@ def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: flo
     hi = min(hi, adj.size(1))
     # a window of row pointers addresses the same col / val arrays: no copy
     dx = ops.spmm_csr(t_rowptr[lo:hi + 1], t_col, t_val, dy, adj.size(0), "sum", scale, None,
-                      0.0, t_max)
+                      0.0, t_max, row_order=adj.row_order_t(reduce, lo, hi))
     if out_rows > hi - lo:  # x had rows the adjacency never references
         pad = torch.zeros((out_rows - (hi - lo), dy.size(1)), dtype=dy.dtype, device=dy.device)
         dx = torch.cat([dx, pad], dim=0)

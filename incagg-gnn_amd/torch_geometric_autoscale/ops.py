@@ -50,7 +50,7 @@ def _need_cuda(t: Tensor, name: str) -> None:
 def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, n_cols: int,
              reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
              add_scale: float = 0.0, max_row_nnz: int = -1, out: Optional[Tensor] = None,
-             x_halo: Optional[Tensor] = None) -> Tensor:
+             x_halo: Optional[Tensor] = None, row_order: Optional[Tensor] = None) -> Tensor:
     """y = scale * reduce_rows(A, [x ; x_halo]) + add_scale * add   (incagg_spmm_csr_f32).
 
     With ``x_halo`` the source rows ``[x.size(0), n_cols)`` are read from ``x_halo`` -- the
@@ -92,9 +92,24 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(x_halo),
             0 if x_halo is None else _ld(x_halo), n_split, n_rows, n_cols, width,
             REDUCE[reduce], float(scale), _ptr(add), 0 if add is None else _ld(add),
-            float(add_scale), _window_nnz(rowptr32, col32), int(max_row_nnz), _ptr(out), _ld(out),
-            _stream_of(dev)))
+            float(add_scale), _window_nnz(rowptr32, col32), int(max_row_nnz),
+            _row_order_ptr(row_order, n_rows, dev), _ptr(out), _ld(out), _stream_of(dev)))
     return out
+
+
+def _row_order_ptr(row_order: Optional[Tensor], n_rows: int, dev):
+    if row_order is None:
+        return None
+    if row_order.dtype != torch.int32 or row_order.device != dev or row_order.numel() != n_rows \
+            or not row_order.is_contiguous():
+        raise ValueError("row_order must be a contiguous int32 device vector with one entry per row")
+    return _ptr(row_order)
+
+
+def degree_order(rowptr32: Tensor) -> Tensor:
+    """Rows by descending length (stable): the ``row_order`` argument of the aggregation."""
+    deg = rowptr32[1:] - rowptr32[:-1]
+    return torch.argsort(deg, descending=True, stable=True).to(torch.int32)
 
 
 def _window_nnz(rowptr32: Tensor, col32: Tensor) -> int:
@@ -110,7 +125,7 @@ def _window_nnz(rowptr32: Tensor, col32: Tensor) -> int:
 def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor,
                     m_in: Tensor, m_ag: Tensor, reduce: str = "sum", scale: float = 1.0,
                     add: Optional[Tensor] = None, add_scale: float = 0.0, max_row_nnz: int = -1,
-                    out: Optional[Tensor] = None) -> Tensor:
+                    out: Optional[Tensor] = None, row_order: Optional[Tensor] = None) -> Tensor:
     """h = scale * (reduce_rows(A, x - m_in) + m_ag) + add_scale * add."""
     _need_cuda(x, "x")
     dev = x.device
@@ -133,7 +148,8 @@ def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: T
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(m_in), _ld(m_in),
             _ptr(m_ag), _ld(m_ag), n_rows, width, REDUCE[reduce], float(scale), _ptr(add),
             0 if add is None else _ld(add), float(add_scale), int(col32.numel()),
-            int(max_row_nnz), _ptr(out), _ld(out), _stream_of(dev)))
+            int(max_row_nnz), _row_order_ptr(row_order, n_rows, dev), _ptr(out), _ld(out),
+            _stream_of(dev)))
     return out
 
 

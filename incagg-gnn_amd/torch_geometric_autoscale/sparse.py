@@ -179,6 +179,8 @@ class SparseTensor:
             out._host = self if self._device.type == "cpu" else self._host
             out._transposed = {}
             out._max_row_nnz = self.max_row_nnz()
+            out._orders = {"rows": ops.degree_order(self._rowptr32()).to(
+                out._device, non_blocking=non_blocking)}
             out.storage = _Storage(out)
             if hasattr(self, "_halo_plan"):
                 out._halo_plan = self._halo_plan
@@ -277,6 +279,23 @@ class SparseTensor:
             v = v.to(torch.float32)
         return self._rowptr32(), self._col32(), v
 
+    def row_order(self) -> Tensor:
+        """Rows by descending length, on the device.  Built on the host when the adjacency is
+        uploaded (part of batch construction), else on first use."""
+        cache = self.__dict__.setdefault("_orders", {})
+        if "rows" not in cache:
+            cache["rows"] = ops.degree_order(self._rowptr32())
+        return cache["rows"]
+
+    def row_order_t(self, reduce: str, lo: int, hi: int) -> Tensor:
+        """The same for rows [lo, hi) of the transposed CSR (device_csr_t prepares the two
+        windows the backward pass uses: all columns, and the in-batch columns)."""
+        cache = self.__dict__.setdefault("_orders", {})
+        key = ("t", lo, hi)
+        if key not in cache:
+            cache[key] = ops.degree_order(self.device_csr_t(reduce)[0][lo:hi + 1])
+        return cache[key]
+
     def device_csr_t(self, reduce: str = "sum"):
         """Transposed CSR for dX = A^T dY, with 1/len(row) folded in for 'mean'."""
         key = "mean" if reduce == "mean" else "sum"
@@ -289,6 +308,11 @@ class SparseTensor:
             max_nnz = int(cnt.max()) if cnt.numel() else 0
             dev = self._device
             self._transposed[key] = (t_rowptr.to(dev), t_col.to(dev), t_val.to(dev), max_nnz)
+            if dev.type == "cuda":
+                orders = self.__dict__.setdefault("_orders", {})
+                n_r, n_c = self._sizes
+                for lo, hi in {(0, n_c), (0, min(n_r, n_c))}:
+                    orders[("t", lo, hi)] = ops.degree_order(t_rowptr[lo:hi + 1]).to(dev)
         return self._transposed[key]
 
     # ------------------------------------------------------------------ aggregation

@@ -75,24 +75,29 @@ int incagg_check_device_errors(void);
  *   nnz: number of edges (= rowptr[n_rows] - rowptr[0]; the host cannot read it from the
  *     device array), used to pick the kernel variant by average row length.
  *   max_row_nnz: length of the longest row if the caller knows it, else -1.
+ *   row_order (may be NULL): device int32[n_rows], a permutation of the rows in which rows
+ *     of similar length are neighbours; only the processing order changes (the variant that
+ *     runs 8 rows per wave uses it to balance its lane groups), never the result layout.
  *   y[n_rows, width] ld = ldy; must not alias x.
  *   width <= 1024 when every pointer is 16-byte aligned and every ld a multiple
  *   of 4, else width <= 256.
  *
- * Two kernel variants, chosen by shape: whole rows per wave, or (width >= 64, one source
- * matrix, >= 16 edges per row on average) 128-byte feature slices pinned to one XCD each so
- * that every source byte has a single home L2.  Rows longer than 128 (256) edges are cut
- * into 64 (128)-edge slices that are summed onto the row with fp32 atomics by a second
- * launch (skipped when max_row_nnz says there is no such row), so such rows are
- * reproducible only up to fp32 rounding order.  The slice queue is device memory the library allocates once per
+ * Three kernel variants, chosen by shape: whole rows per wave; 128-byte feature slices
+ * pinned to one XCD each so that every source byte has a single home L2, one row per wave
+ * (width >= 64, one source matrix, >= 16 edges per row on average); and the same slices
+ * with 8 rows per wave (whenever row_order is given and the rows are 16-byte aligned).
+ * Rows longer than 128 (256 in the second variant) edges are cut into 64 (128)-edge slices
+ * that are summed onto the row with fp32 atomics by a second launch (skipped when
+ * max_row_nnz says there is no such row), so such rows are reproducible only up to fp32
+ * rounding order.  The slice queue is device memory the library allocates once per
  * (device, stream) on the first call that may need it.
  */
 int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                         const float *x, int64_t ldx, const float *x_halo, int64_t ld_halo,
                         int64_t n_split, int64_t n_rows, int64_t n_cols, int64_t width,
                         int reduce, float scale, const float *add, int64_t ldadd,
-                        float add_scale, int64_t nnz, int64_t max_row_nnz, float *y,
-                        int64_t ldy, void *stream);
+                        float add_scale, int64_t nnz, int64_t max_row_nnz,
+                        const int32_t *row_order, float *y, int64_t ldy, void *stream);
 
 /*
  * Fused incremental aggregate (the fork's contribution):
@@ -108,13 +113,16 @@ int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col, const 
                                int64_t ldin, const float *m_ag, int64_t ldag,
                                int64_t n_rows, int64_t width, int reduce, float scale,
                                const float *add, int64_t ldadd, float add_scale, int64_t nnz,
-                               int64_t max_row_nnz, float *h, int64_t ldh, void *stream);
+                               int64_t max_row_nnz, const int32_t *row_order, float *h,
+                               int64_t ldh, void *stream);
 
 /*
  * Launch tuning of the aggregation (no counterpart in the reference; for benchmarks and
- * tests).  Keys: "spmm_sliced" (-1 choose by shape, 0 whole rows per wave, 1 feature slices),
- * "hub_threshold", "hub_slice", "hub_blocks", "sliced_hub_threshold", "sliced_hub_slice",
- * "sliced_rows_per_wave".  Not thread-safe against concurrent aggregation calls.
+ * tests).  Keys: "spmm_sliced" (-1 choose by shape, 0 whole rows per wave, 1 feature slices
+ * with one row per wave, 2 feature slices with 8 rows per wave), "hub_threshold", "hub_slice",
+ * "hub_blocks", "sliced_hub_threshold", "sliced_hub_slice", "sliced_rows_per_wave",
+ * "grouped_hub_threshold", "grouped_hub_slice".  Not thread-safe against concurrent
+ * aggregation calls.
  */
 int incagg_set_tuning(const char *key, int value);
 

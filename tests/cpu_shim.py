@@ -15,8 +15,16 @@ def _np(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
+def _check_order(row_order, n_rows):
+    # the processing order must be a permutation of the rows the call addresses
+    if row_order is not None:
+        assert row_order.dtype == torch.int32 and row_order.numel() == n_rows
+        assert torch.equal(torch.sort(row_order.to(torch.int64)).values, torch.arange(n_rows))
+
+
 def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None, add_scale=0.0,
-              max_row_nnz=-1, out=None, x_halo=None):
+              max_row_nnz=-1, out=None, x_halo=None, row_order=None):
+    _check_order(row_order, rowptr32.numel() - 1)
     if x_halo is not None:
         x = torch.cat([x, x_halo], dim=0)
     y = cp.spmm(_np(rowptr32).astype(np.int64), _np(col32).astype(np.int64), _np(val),
@@ -31,7 +39,8 @@ def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None
 
 
 def _spmm_csr_incagg(rowptr32, col32, val, x, m_in, m_ag, reduce="sum", scale=1.0, add=None,
-                     add_scale=0.0, max_row_nnz=-1, out=None):
+                     add_scale=0.0, max_row_nnz=-1, out=None, row_order=None):
+    _check_order(row_order, rowptr32.numel() - 1)
     b, w = rowptr32.numel() - 1, x.size(1)
     h = cp.incagg(_np(rowptr32).astype(np.int64), _np(col32).astype(np.int64), _np(val),
                   _np(x[:b]), _np(m_in[:b, :w]), _np(m_ag[:b, :w]), reduce)

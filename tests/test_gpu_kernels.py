@@ -27,13 +27,21 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=["rows", "sliced", "auto"])
+@pytest.fixture(params=["rows", "sliced", "grouped", "grouped_sorted", "auto"])
 def variant(request):
-    """Forces the whole-row or the feature-sliced aggregation kernel (or the shape heuristic)."""
+    """Forces one aggregation kernel: whole rows per wave, feature slices with one row per wave,
+    feature slices with 8 rows per wave (identity order / the degree-sorted order that the
+    shape heuristic keys on), or the heuristic without an order."""
     from torch_geometric_autoscale import _lib
-    _lib.set_tuning("spmm_sliced", {"rows": 0, "sliced": 1, "auto": -1}[request.param])
+    _lib.set_tuning("spmm_sliced", {"rows": 0, "sliced": 1, "grouped": 2, "grouped_sorted": -1,
+                                    "auto": -1}[request.param])
     yield request.param
     _lib.set_tuning("spmm_sliced", -1)
+
+
+def _ro(variant, rowptr32):
+    from torch_geometric_autoscale import ops as _ops
+    return _ops.degree_order(rowptr32) if variant == "grouped_sorted" else None
 
 
 def _dev_csr(rowptr, col, val, dev):
@@ -67,7 +75,7 @@ def test_spmm_matches_oracle(ops, dev, width, reduce, variant):
     rp, c, v = _dev_csr(rowptr, col, val, dev)
     xd = torch.from_numpy(x).to(dev)
     for hint in (-1, int(np.diff(rowptr).max())):
-        y = ops.spmm_csr(rp, c, v, xd, n_cols, reduce, max_row_nnz=hint)
+        y = ops.spmm_csr(rp, c, v, xd, n_cols, reduce, max_row_nnz=hint, row_order=_ro(variant, rp))
         _check(y, y64, y32)
     _lib.check_device_errors()
 
@@ -82,7 +90,8 @@ def test_spmm_epilogue_and_strides(ops, dev, variant):
     y64 = 0.9 * cp.spmm_f64(rowptr, col, val, x) + 0.1 * add[:n_rows].astype(np.float64)
     rp, c, v = _dev_csr(rowptr, col, val, dev)
     xd = torch.from_numpy(xfull).to(dev)[:, :width]          # ld = 2 * width
-    y = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", 0.9, torch.from_numpy(add).to(dev), 0.1)
+    y = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", 0.9, torch.from_numpy(add).to(dev), 0.1,
+                     row_order=_ro(variant, rp))
     _check(y, y64)
 
 
@@ -96,11 +105,13 @@ def test_spmm_hub_rows_sliced(ops, dev, variant):
         v_in = val if reduce == "sum" else None
         y64 = cp.spmm_f64(rowptr, col, v_in, x, reduce)
         rp, c, v = _dev_csr(rowptr, col, v_in, dev)
-        y = ops.spmm_csr(rp, c, v, torch.from_numpy(x).to(dev), n_cols, reduce)
+        y = ops.spmm_csr(rp, c, v, torch.from_numpy(x).to(dev), n_cols, reduce,
+                         row_order=_ro(variant, rp))
         tol = 1e-4 + 1e-4 * np.abs(y64) + 1e-6 * np.sqrt(6000)  # long fp32 sums
         assert np.all(np.abs(y.cpu().numpy() - y64) <= tol)
     # called twice in a row: the slice queue must be clean for the second call
-    y2 = ops.spmm_csr(rp, c, v, torch.from_numpy(x).to(dev), n_cols, "mean")
+    y2 = ops.spmm_csr(rp, c, v, torch.from_numpy(x).to(dev), n_cols, "mean",
+                      row_order=_ro(variant, rp))
     assert torch.allclose(y, y2, rtol=1e-5, atol=1e-5)
 
 
@@ -125,6 +136,25 @@ def test_spmm_bad_column_is_skipped_and_reported(ops, dev):
     _lib.check_device_errors()  # latch cleared
 
 
+def test_spmm_row_order_is_validated(ops, dev):
+    """A row_order entry outside [0, n_rows) is not followed: it is reported, and the call's
+    other rows are still written."""
+    from torch_geometric_autoscale import _lib
+    rp = torch.tensor([0, 1, 2, 3], dtype=torch.int32, device=dev)
+    c = torch.tensor([0, 1, 2], dtype=torch.int32, device=dev)
+    x = torch.arange(12, dtype=torch.float32, device=dev).view(3, 4)
+    with pytest.raises(ValueError):
+        ops.spmm_csr(rp, c, None, x, 3, row_order=torch.tensor([0, 1], dtype=torch.int32, device=dev))
+    bad = torch.tensor([2, 7, 0], dtype=torch.int32, device=dev)
+    y = ops.spmm_csr(rp, c, None, x, 3, row_order=bad)
+    assert torch.equal(y[[0, 2]].cpu(), x[[0, 2]].cpu())
+    with pytest.raises(RuntimeError):
+        _lib.check_device_errors()
+    good = torch.tensor([2, 1, 0], dtype=torch.int32, device=dev)
+    assert torch.equal(ops.spmm_csr(rp, c, None, x, 3, row_order=good).cpu(), x.cpu())
+    _lib.check_device_errors()
+
+
 @pytest.mark.parametrize("width", [256, 128, 41, 512])
 @pytest.mark.parametrize("reduce", ["sum", "mean"])
 def test_incagg_matches_oracle(ops, dev, width, reduce, variant):
@@ -142,10 +172,11 @@ def test_incagg_matches_oracle(ops, dev, width, reduce, variant):
     rp, c, v = _dev_csr(rowptr, col, val, dev)
     args = (rp, c, v, torch.from_numpy(x).to(dev), torch.from_numpy(m_in).to(dev)[:b, :width],
             torch.from_numpy(m_ag).to(dev)[:b, :width], reduce)
-    _check(ops.spmm_csr_incagg(*args), h64, h32)
+    _check(ops.spmm_csr_incagg(*args, row_order=_ro(variant, rp)), h64, h32)
     # with the epilogue: scale * (agg + m_ag) + add_scale * add
     add = rng.standard_normal((b, width)).astype(np.float32)
-    h = ops.spmm_csr_incagg(*args, 0.9, torch.from_numpy(add).to(dev), 0.1)
+    h = ops.spmm_csr_incagg(*args, 0.9, torch.from_numpy(add).to(dev), 0.1,
+                            row_order=_ro(variant, rp))
     _check(h, 0.9 * h64 + 0.1 * add)
     # the two-pass form agrees
     d = ops.rows_sub(args[3], args[4])
@@ -244,18 +275,19 @@ def test_full_size_properties(ops, dev, variant):
     g = torch.Generator(device=dev).manual_seed(0)
     x1 = torch.randn(m, width, device=dev, generator=g)
     x2 = torch.randn(m, width, device=dev, generator=g)
-    y1 = ops.spmm_csr(rp, c, v, x1, m)
-    y2 = ops.spmm_csr(rp, c, v, x2, m)
-    y12 = ops.spmm_csr(rp, c, v, x1 + 2 * x2, m)
+    ro = _ro(variant, rp)
+    y1 = ops.spmm_csr(rp, c, v, x1, m, row_order=ro)
+    y2 = ops.spmm_csr(rp, c, v, x2, m, row_order=ro)
+    y12 = ops.spmm_csr(rp, c, v, x1 + 2 * x2, m, row_order=ro)
     err = (y12 - (y1 + 2 * y2)).abs().max().item()
     assert err <= 2e-3, err                      # hub rows sum 17k terms in fp32
     ones = torch.ones(m, width, device=dev)
-    rs = ops.spmm_csr(rp, c, v, ones, m)
+    rs = ops.spmm_csr(rp, c, v, ones, m, row_order=ro)
     want = np.add.reduceat(np.concatenate([val, [0]]).astype(np.float64),
                            np.minimum(rowptr[:-1], val.size))
     want[np.diff(rowptr) == 0] = 0
     assert np.allclose(rs[:, 0].cpu().numpy(), want, atol=2e-3)
-    mean1 = ops.spmm_csr(rp, c, None, ones * 3, m, "mean")
+    mean1 = ops.spmm_csr(rp, c, None, ones * 3, m, "mean", row_order=ro)
     nonempty = torch.from_numpy(np.diff(rowptr) > 0).to(dev)
     assert torch.allclose(mean1[nonempty], torch.full_like(mean1[nonempty], 3.0), atol=1e-4)
     # gather then scatter back is the identity on a History-sized table
