@@ -63,6 +63,9 @@ class KernelClock:
     def __init__(self):
         self.records = []   # (start, end, algorithmic_bytes, gather_bytes, edges)
         self.enabled = False
+        # distinct source rows of an edge array, where the call's n_cols is not that number
+        # (out-of-batch rows read in place from a whole History table): col data_ptr -> count
+        self.sources = {}
 
     def wrap(self, ops):
         inner = ops.spmm_csr
@@ -78,8 +81,9 @@ class KernelClock:
             n_rows, nnz, f = rowptr32.numel() - 1, col32.numel(), x.size(1)
             # compulsory traffic: indices + weights, row pointers, every distinct source row
             # once, every destination row once (source rows touched <= n_cols)
+            n_src = clock.sources.get(col32.data_ptr(), min(n_cols, nnz))
             algo = nnz * (4 + (4 if val is not None else 0)) + (n_rows + 1) * 4 \
-                + min(n_cols, nnz) * f * 4 + n_rows * f * 4
+                + n_src * f * 4 + n_rows * f * 4
             gather = nnz * (f * 4 + 8) + n_rows * f * 4
             clock.records.append((s, e, algo, gather, nnz))
             return y
@@ -201,6 +205,11 @@ def main():
         adj = sub.data.adj_t.to(dev)
         t_rowptr = adj.device_csr_t("sum")[0]       # backward CSR, once per batch
         nid_dev = sub.n_id.to(dev)
+        if args.mode == "gas" and nid_dev.numel() > sub.batch_size:
+            # column ids for reading out-of-batch rows in place from the History tables:
+            # part of batch construction, like the backward CSR
+            cip = adj.col_in_place(nid_dev[sub.batch_size:], sub.batch_size)
+            clock.sources[cip.data_ptr()] = int(nid_dev.numel())
         e_all, e_ib = adj.nnz(), int(t_rowptr[sub.batch_size])
         # edges aggregated per step: L forward aggregations over all E edges; backward:
         # layer 0 over all E (its input is computed from features for every row), layers
@@ -335,7 +344,7 @@ def main():
             line["roofline"] = {
                 "bound": "hbm", "achieved": ks["algo_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ks["algo_GBps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(args),
-                "kernel": "spmm_rows_kernel (+ spmm_hub_kernel), forward and transposed launches",
+                "kernel": "spmm_grouped_kernel (+ spmm_sliced_hub_kernel), forward and transposed launches",
                 "avg_launch_ms": ks["avg_ms"], "launches": ks["launches"],
                 "algorithmic_bytes_per_launch": ks["algo_bytes_per_launch"],
                 "gather_bound_GBps": ks["gather_GBps"],

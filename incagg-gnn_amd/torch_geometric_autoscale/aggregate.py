@@ -29,13 +29,19 @@ def _as_rows(x: Tensor) -> Tensor:
 
 class _SpMM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x_halo, add, adj, reduce, scale, add_scale):
+    def forward(ctx, x, x_halo, add, adj, reduce, scale, add_scale, halo_ids):
         rowptr, col, val = adj.device_csr()
-        y = ops.spmm_csr(rowptr, col, val, x, adj.size(1), reduce, scale, add, add_scale,
+        n_cols = adj.size(1)
+        if halo_ids is not None:
+            # out-of-batch column c reads row halo_ids[c - B] of the table x_halo in place
+            col = adj.col_in_place(halo_ids, x.size(0))
+            n_cols = x.size(0) + x_halo.size(0)
+        y = ops.spmm_csr(rowptr, col, val, x, n_cols, reduce, scale, add, add_scale,
                          adj.max_row_nnz(), x_halo=x_halo, row_order=adj.row_order())
         ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
         ctx.x_rows = x.size(0)
         ctx.halo_rows = None if x_halo is None else x_halo.size(0)
+        ctx.in_place = halo_ids is not None
         ctx.has_add = add is not None
         return y
 
@@ -54,11 +60,14 @@ class _SpMM(torch.autograd.Function):
                 dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, 0, ctx.x_rows,
                                            ctx.x_rows)
             if ctx.needs_input_grad[1]:
+                if ctx.in_place:
+                    raise RuntimeError("rows consumed in place from a History table are "
+                                       "constants: the table must not require a gradient")
                 dhalo = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, ctx.x_rows,
                                               n_cols, ctx.halo_rows)
         if ctx.has_add and ctx.needs_input_grad[2]:
             dadd = dy * ctx.add_scale
-        return dx, dhalo, dadd, None, None, None, None
+        return dx, dhalo, dadd, None, None, None, None, None
 
 
 class _IncAgg(torch.autograd.Function):
@@ -101,13 +110,17 @@ def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: flo
 
 def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
          add: Optional[Tensor] = None, add_scale: float = 0.0,
-         x_halo: Optional[Tensor] = None) -> Tensor:
+         x_halo: Optional[Tensor] = None, halo_ids: Optional[Tensor] = None) -> Tensor:
     """``adj @ x`` / ``spmm(adj, x, reduce)`` with an optional fused ``+ add_scale * add``.
 
     ``x_halo``: the source rows are ``[x ; x_halo]`` without concatenating them -- ``x``
     the fresh in-batch rows, ``x_halo`` the pulled out-of-batch History rows.  The
     backward pass then aggregates only over the columns of ``x`` (and of ``x_halo`` if
-    it requires a gradient, which pulled rows never do)."""
+    it requires a gradient, which pulled rows never do).
+
+    ``halo_ids`` (device int64, one per out-of-batch column): ``x_halo`` is then a whole
+    History table and column ``B + k`` reads its row ``halo_ids[k]`` in place -- the pull
+    (history.py:33-39) folded into the aggregation, no gathered copy is ever written."""
     if reduce not in ("sum", "add", "mean"):
         raise ValueError(f"unsupported reduce '{reduce}'")
     x = _as_rows(x)
@@ -115,8 +128,10 @@ def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
         add = _as_rows(add)
     if x_halo is not None:
         x_halo = _as_rows(x_halo)
+    if halo_ids is not None and x_halo is None:
+        raise ValueError("halo_ids needs the table to read from (x_halo)")
     return _SpMM.apply(x, x_halo, add, adj, "mean" if reduce == "mean" else "sum", float(scale),
-                       float(add_scale))
+                       float(add_scale), halo_ids)
 
 
 def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,
@@ -139,7 +154,7 @@ def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,
     # two-pass form: one streaming subtract, then the plain aggregation with M_ag
     # folded in afterwards; gathers touch one operand instead of two.
     d = _RowsSub.apply(x[:b], m_in)
-    h = _SpMM.apply(d, None, None, adj, red, 1.0, 0.0) + m_ag[:b, :x.size(1)]
+    h = _SpMM.apply(d, None, None, adj, red, 1.0, 0.0, None) + m_ag[:b, :x.size(1)]
     if scale != 1.0:
         h = h * scale
     if add is not None:

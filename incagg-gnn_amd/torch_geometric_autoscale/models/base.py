@@ -71,6 +71,10 @@ class ScalableGNN(torch.nn.Module):
         # this rank's rows (construct the model with num_nodes = ctx.local_rows)
         self.partition_ctx = None
         self._current_plan = None
+        # push/pull forward and refresh sweeps: let the aggregation read out-of-batch rows
+        # straight from the HBM-resident table (no gathered copy) whenever nothing has to
+        # touch those rows first (no dropout on them, no per-row transform before aggregating)
+        self.halo_in_place = True
 
     # ------------------------------------------------------------------ placement
     @property
@@ -146,8 +150,9 @@ class ScalableGNN(torch.nn.Module):
     def _adj(self, adj_t: SparseTensor) -> SparseTensor:
         return unweighted(adj_t) if self.agg_reduce == "mean" else adj_t
 
-    def _aggregate(self, adj_t: SparseTensor, x: Tensor) -> Tensor:
-        return spmm(self._adj(adj_t), x, reduce=self.agg_reduce)
+    def _aggregate(self, adj_t: SparseTensor, x: Tensor, halo: Optional[Tensor] = None,
+                   halo_ids: Optional[Tensor] = None) -> Tensor:
+        return spmm(self._adj(adj_t), x, reduce=self.agg_reduce, x_halo=halo, halo_ids=halo_ids)
 
     def _drop(self, x: Tensor) -> Tensor:
         p = getattr(self, "dropout", 0.0)
@@ -257,32 +262,48 @@ class ScalableGNN(torch.nn.Module):
         self.pool.free_pull()
         return out, 0.0
 
+    def _in_place_ok(self, history, x: Tensor) -> bool:
+        if not self.halo_in_place or self._async or self.partition_ctx is not None:
+            return False
+        if not _same_device(history.emb.device, x.device):
+            return False
+        if type(self)._pre_aggregate is not ScalableGNN._pre_aggregate:
+            return False
+        drops = self.training and self._layer_dropout and getattr(self, "dropout", 0.0) > 0
+        return not drops and history.emb.size(1) >= x.size(1)
+
     def _push_and_pull_split(self, history, x: Tensor, batch_size: Optional[int],
                              n_id: Optional[Tensor], offset: Optional[Tensor],
-                             count: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
+                             count: Optional[Tensor]
+                             ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
         """:meth:`push_and_pull` without the concatenation: returns the fresh in-batch rows
-        and, separately, the pulled out-of-batch rows (``None`` when nothing is pulled).
-        The aggregation kernel reads its source rows from the two pieces, and gradients
-        only ever flow into the first.  With staging pools the second piece is a view into
-        slot memory that stays valid until :meth:`_release_halo`."""
+        and, separately, the out-of-batch rows (``None`` when there are none) plus, when
+        those are to be read in place, their row ids: ``(x, table, ids)`` instead of
+        ``(x, pulled_rows, None)``.  The aggregation kernel reads its source rows from the
+        two pieces, and gradients only ever flow into the first.  With staging pools the
+        second piece is a view into slot memory that stays valid until
+        :meth:`_release_halo`."""
         if n_id is None or batch_size is None:
             out, _ = self.push_and_pull(history, x, batch_size, n_id, offset, count)
-            return out, None
+            return out, None, None
         x = x if x.size(0) == batch_size else x[:batch_size]
         if self.partition_ctx is not None:
             # push into the local shard first, then serve / fetch: peers asking for rows of
             # this very batch get the fresh values
             history.push(x.detach(), n_id[:batch_size], self._local(offset), count)
             plan = self._current_plan
-            return x, (None if plan is None else plan.exchange(history.emb))
+            return x, (None if plan is None else plan.exchange(history.emb)), None
         if not self._async:
             history.push(x.detach(), n_id[:batch_size], offset, count)
-            halo = history.pull(n_id[batch_size:]) if n_id.numel() > batch_size else None
-            return x, halo
+            if n_id.numel() <= batch_size:
+                return x, None, None
+            if self._in_place_ok(history, x):
+                return x, history.emb[:, :x.size(1)], n_id[batch_size:]
+            return x, history.pull(n_id[batch_size:]), None
         halo = self.pool.synchronize_pull()[:n_id.numel() - batch_size]
         self.pool.async_push(x.detach(), offset, count, history.emb)
         self._halo_in_slot = True
-        return x, halo
+        return x, halo, None
 
     def _release_halo(self) -> None:
         """The kernels reading the pulled rows have been launched: hand the staging slot back
@@ -349,32 +370,34 @@ class ScalableGNN(torch.nn.Module):
         if not use_aggregation:
             x = x[:b]
         adj = self._adj(adj_t)
-        halo = None  # pulled out-of-batch rows of the current layer input (never concatenated)
+        # out-of-batch rows of the current layer input (never concatenated): pulled rows, or
+        # the whole table plus the row ids when they are read in place
+        halo = halo_ids = None
         for i in range(self.num_layers):
             x = self._layer_input(i, x)
             if not use_aggregation:
                 h = self._update(i, x[:b], x, state)
             else:
-                if halo is not None:
+                if halo is not None and halo_ids is None:
                     halo = self._layer_input(i, halo)
                 mix = self._mix(i, state, b)
                 xa = self._pre_aggregate(i, x)
                 if mix is not None:
-                    agg = spmm(adj, x, self.agg_reduce, *mix, x_halo=halo)
+                    agg = spmm(adj, x, self.agg_reduce, *mix, x_halo=halo, halo_ids=halo_ids)
                     h = self._update_mixed(i, agg, x, state)
                 elif xa is not None:
                     ha = None if halo is None else self._pre_aggregate(i, halo)
                     agg = spmm(adj, xa, reduce=self.agg_reduce, x_halo=ha)
                     h = self._update(i, agg, x, state, pre=True)
                 else:
-                    agg = spmm(adj, x, reduce=self.agg_reduce, x_halo=halo)
+                    agg = spmm(adj, x, reduce=self.agg_reduce, x_halo=halo, halo_ids=halo_ids)
                     h = self._update(i, agg, x, state)
                 self._release_halo()
             if i < self.num_layers - 1:
                 nid = None if n_id is None else n_id.to(self.emb_device)
                 if use_aggregation:
-                    x, halo = self._push_and_pull_split(self.histories[i + 1], h, batch_size, nid,
-                                                        offset, count)
+                    x, halo, halo_ids = self._push_and_pull_split(self.histories[i + 1], h,
+                                                                  batch_size, nid, offset, count)
                 else:
                     x, _ = self.push_only(self.histories[i + 1], h, batch_size, nid, offset, count)
             else:
@@ -470,10 +493,20 @@ class ScalableGNN(torch.nn.Module):
         sharded = self.partition_ctx is not None
         if sharded and use_pool:
             raise NotImplementedError("partition-parallel runs keep their table shards in HBM")
+        in_place = (self.halo_in_place and not use_pool and not sharded
+                    and _same_device(self.emb_device, self.device))
 
-        def run_layer(i, x, adj_t, batch_size, offset, count, state):
+        def ids_on_device(data, n_id):     # one upload per (static) evaluation batch
+            cached = data.__dict__.get("_n_id_dev")
+            if cached is None or cached.device != self.device or cached.numel() != n_id.numel():
+                cached = n_id.to(self.device)
+                data.__dict__["_n_id_dev"] = cached   # beside the attribute store, not in it
+            return cached
+
+        def run_layer(i, x, adj_t, batch_size, offset, count, state, halo=None, halo_ids=None):
             offset = self._local(offset)
-            agg = self._aggregate(adj_t, x) if use_aggregation else x[:batch_size]
+            agg = (self._aggregate(adj_t, x, halo, halo_ids) if use_aggregation
+                   else x[:batch_size])
             if with_aggregates:
                 self._push_rows(self.histories_ag[i].emb, agg, offset, count, pool_ag)
             out = self._update(i, agg, x, state)[:batch_size]
@@ -503,12 +536,23 @@ class ScalableGNN(torch.nn.Module):
                     plan.exchange(self.histories[i].emb)
                     continue
                 adj_t = data.adj_t.to(self.device)
+                halo = halo_ids = None
                 if use_pool:
                     x = pool.synchronize_pull()[:n_id.numel()]
+                elif in_place and use_aggregation and n_id.numel() > batch_size:
+                    # in-batch rows by chunks (the update needs them); out-of-batch rows are
+                    # read from the table by the aggregation itself
+                    hist = self.histories[i]
+                    x = torch.empty((batch_size, hist.embedding_dim), dtype=hist.emb.dtype,
+                                    device=self.device)
+                    ops.copy_row_chunks(x, hist.emb, offset, count, packed_is_src=False,
+                                        device=self.device)
+                    halo = hist.emb
+                    halo_ids = ids_on_device(data, n_id)[batch_size:]
                 else:
                     x = self._pull_layer_input(self.histories[i], batch_size, n_id, offset, count,
                                                plan)
-                run_layer(i, x, adj_t, batch_size, offset, count, state)
+                run_layer(i, x, adj_t, batch_size, offset, count, state, halo, halo_ids)
                 if use_pool:
                     pool.free_pull()
             if use_pool:
@@ -527,6 +571,11 @@ class ScalableGNN(torch.nn.Module):
         ``histories_ag`` (M_ag) (e.g. models/gcn2.py:433-507).  The aggregate of a
         layer's input is computed once and used for M_ag and for the layer itself."""
         return self._sweep(loader, use_aggregation, with_aggregates=True)
+
+
+def _same_device(a, b) -> bool:
+    a, b = torch.device(a), torch.device(b)
+    return a.type == b.type and (a.index or 0) == (b.index or 0)
 
 
 def in_batch_columns(adj_t: SparseTensor, batch_size: int) -> SparseTensor:

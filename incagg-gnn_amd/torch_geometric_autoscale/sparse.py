@@ -279,6 +279,25 @@ class SparseTensor:
             v = v.to(torch.float32)
         return self._rowptr32(), self._col32(), v
 
+    def col_in_place(self, halo_ids: Tensor, n_in_batch: int) -> Tensor:
+        """Column ids for reading out-of-batch source rows straight from a History table:
+        columns below ``n_in_batch`` unchanged, column ``c`` above it becomes
+        ``n_in_batch + halo_ids[c - n_in_batch]`` (int32, device; built once per adjacency
+        and id vector)."""
+        # one entry: an adjacency belongs to one batch, i.e. one id vector
+        key = (halo_ids.data_ptr(), halo_ids.numel(), n_in_batch)
+        hit = self.__dict__.get("_in_place_cols")
+        if hit is None or hit[0] != key:
+            if halo_ids.numel() < self._sizes[1] - n_in_batch:
+                raise ValueError("halo_ids does not cover the out-of-batch columns")
+            col = self._col32().to(torch.int64)
+            ids = halo_ids.to(device=col.device, dtype=torch.int64)
+            moved = n_in_batch + ids[(col - n_in_batch).clamp_(min=0)] if ids.numel() else col
+            out = torch.where(col < n_in_batch, col, moved).to(torch.int32)
+            hit = (key, out, halo_ids)    # the id vector is kept alive with its address
+            self._in_place_cols = hit
+        return hit[1]
+
     def row_order(self) -> Tensor:
         """Rows by descending length, on the device.  Built on the host when the adjacency is
         uploaded (part of batch construction), else on first use."""

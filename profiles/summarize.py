@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses a `rocprofv3 --kernel-trace --stats --output-format csv` directory into a short
 per-kernel table for the timed steps of bench.py (the last `steps` x 16 aggregation launches
-mark the timed region).  Usage: summarize.py <rocprof_dir> <steps> > summary.txt"""
+mark the timed region).  Usage: summarize.py <rocprof_dir> <steps> [aggregations_per_step [last_step_sequence.txt]] > summary.txt"""
 import collections
 import csv
 import glob
@@ -26,7 +26,8 @@ def main():
     per_step_aggs = int(sys.argv[3]) if len(sys.argv) > 3 else 16
     f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if 'spmm_rows_kernel' in r['Kernel_Name']]
+    main_kernels = ('spmm_rows_kernel', 'spmm_sliced_kernel', 'spmm_grouped_kernel')
+    idx = [i for i, r in enumerate(rows) if any(k in r['Kernel_Name'] for k in main_kernels)]
     seg = rows[idx[-steps * per_step_aggs]:]
     t0 = int(seg[0]['Start_Timestamp'])
     t1 = max(int(r['End_Timestamp']) for r in seg)
@@ -43,6 +44,12 @@ def main():
     print(f"{'kernel':78s} {'n/step':>7s} {'ms/step':>8s} {'avg_us':>8s}  vgpr/sgpr/lds")
     for k, (c, dur, res) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
         print(f"{k:78s} {c / steps:7.1f} {dur / steps / 1e6:8.3f} {dur / c / 1e3:8.1f}  {'/'.join(res)}")
+    if len(sys.argv) > 4:   # kernel sequence of the last step, in launch order
+        last = rows[idx[-per_step_aggs]:]
+        with open(sys.argv[4], 'w') as out:
+            for r in last:
+                out.write(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} us  "
+                          f"{short(r['Kernel_Name'])}  grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}\n")
 
 
 if __name__ == '__main__':

@@ -77,6 +77,15 @@ def check_refresh_sweep(name, model, data, ptr, batch_parts=2):
                                    mo.padded(aggs[i], width), **TOL,
                                    err_msg=f"{name}: M_ag of layer {i}")
     np.testing.assert_allclose(out.cpu().numpy(), want, **TOL, err_msg=f"{name}: output")
+    # the sweep with out-of-batch rows gathered into a buffer first writes the same values
+    first = out.clone()
+    model.halo_in_place = False
+    try:
+        second = model.mini_inference_vr(loader=loader)
+    finally:
+        model.halo_in_place = True
+    assert torch.allclose(first, second, rtol=1e-5, atol=1e-6), \
+        f"{name}: gathered vs in-place sweep differ"
     return loader, want
 
 
@@ -109,6 +118,17 @@ def check_push_pull_forward(name, model, data, ptr, want, device):
         assert out.size(0) == b
         np.testing.assert_allclose(out.detach().cpu().numpy(), want[sub.n_id[:b].numpy()], **TOL,
                                    err_msg=f"{name}: push/pull forward, parts {parts}")
+        # out-of-batch rows pulled into a buffer first, or read in place from the table by the
+        # aggregation: same values through the same kernel
+        model.halo_in_place = not model.halo_in_place
+        try:
+            again = model(sub.data.x.to(device), sub.data.adj_t.to(device), b, sub.n_id,
+                          sub.offset, sub.count)["out"]
+        finally:
+            model.halo_in_place = not model.halo_in_place
+        # (rows cut into slices are summed with atomics: equal up to fp32 summation order)
+        assert torch.allclose(again, out, rtol=1e-5, atol=1e-6), \
+            f"{name}: pulled vs in-place halo rows differ"
 
 
 def check_incagg_forward(name, model, data, ptr, device):
