@@ -4,9 +4,10 @@ ogbn-products-sized partitioned graph (BASELINE.json configs[2]: GCN2, 150 parts
 hidden 256), one process per GPU.
 
 A step = one partition batch through the hot path: 8 x (HIP CSR aggregation over the
-batch's [B, M] one-hop adjacency, push of the B fresh rows into the next layer's History
-table, pull of the M - B out-of-batch rows), the dense GCNII updates, the loss, the
-backward pass (8 transposed aggregations) and the Adam step.  Inputs (graph, features,
+batch's [B, M] one-hop adjacency -- its M - B out-of-batch source rows read in place from
+the layer's History table -- and push of the B fresh rows into the next layer's table), the
+dense GCNII updates, the loss, the backward pass (8 transposed aggregations) and the Adam
+step.  Inputs (graph, features,
 History tables) are resident in HBM before the timed region.  `value` counts every edge
 that an aggregation launch processes: L * nnz(adj_t) forward; backward nnz(adj_t) for
 layer 0 plus, for the other layers, the edges whose source row is in the batch (the
@@ -105,7 +106,7 @@ class KernelClock:
 def pmc_traffic(args):
     """Fabric bytes per aggregation launch from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs of this very
-    command, FETCH_SIZE doubled as gfx950 requires).  Counters cannot be read from inside
+    command reduced by profiles/pmc_traffic.py, FETCH_SIZE doubled as gfx950 requires).  Counters cannot be read from inside
     the process, so the figure is only reported for the workload it was measured on."""
     default = (args.dataset, args.parts, args.layers, args.hidden, args.scale, args.cross,
                args.mode) == ("products", 150, 8, 256, 1.0, 0.15, "gas")

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Fabric traffic per aggregation launch from two rocprofv3 PMC passes of bench.py
+(`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, one run each, csv output).  Both counters are in
+KiB-sized units of 1024 B as rocprofv3 reports them for gfx950; FETCH_SIZE counts 128-byte
+requests at 64 B and is doubled (checked against a pure row gather of known size, see
+r01_pmc_notes.txt), WRITE_SIZE is exact.  A "launch" is one call of the aggregation entry
+point: the main kernel plus, when rows were cut into slices, the slice kernel.
+Usage: pmc_traffic.py <fetch_dir> <write_dir> <steps> <launches_per_step> > traffic.json"""
+import csv
+import glob
+import json
+import sys
+
+MAIN = ("spmm_rows_kernel", "spmm_sliced_kernel", "spmm_grouped_kernel")
+SECOND = ("spmm_hub_kernel", "spmm_sliced_hub_kernel")
+
+
+def per_launch(d, counter, steps, per_step):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    mains = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in MAIN)]
+    first = mains[-steps * per_step]
+    total = sum(float(r["Counter_Value"]) for r in rows[first:]
+                if any(k in r["Kernel_Name"] for k in MAIN + SECOND))
+    return total / (steps * per_step)
+
+
+def main():
+    fetch_dir, write_dir, steps, per_step = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    fetch = per_launch(fetch_dir, "FETCH_SIZE", steps, per_step)
+    write = per_launch(write_dir, "WRITE_SIZE", steps, per_step)
+    print(json.dumps({
+        "workload": "bench.py default (gas, products, 150 parts, F=256), timed steps",
+        "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
+        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is",
+        "traffic_bytes_per_launch": (2 * fetch + write) * 1024,
+    }, indent=1))
+
+
+if __name__ == "__main__":
+    main()
