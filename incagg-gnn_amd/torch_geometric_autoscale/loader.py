@@ -79,6 +79,43 @@ def partition_batch(data: Data, ptr: Tensor, part_ids, in_batch_only: bool = Fal
     return SubData(out, batch_size, n_id, offset, count)
 
 
+def _device_graph(adj_t: SparseTensor, device):
+    """The global CSR resident in HBM (int64 indices as the relabelling takes them, fp32
+    values), uploaded once per graph and device."""
+    cache = adj_t.__dict__.setdefault("_device_graph", {})
+    device = torch.device(device)
+    if device not in cache:
+        rowptr, col, value = adj_t.csr()
+        cache[device] = (rowptr.to(device), col.to(device),
+                         None if value is None else value.to(device, torch.float32))
+    return cache[device]
+
+
+def device_partition_batch(data: Data, ptr: Tensor, part_ids, device,
+                           in_batch_only: bool = False) -> SubData:
+    """:func:`partition_batch` with the batch built on the GPU: the relabelling
+    (csrc/cpu/relabel_cpu.cpp) runs as HIP kernels over the HBM-resident graph and emits the
+    device-format adjacency directly; same ``n_id`` order, same local ids, same values as
+    the host path, element for element.  ``n_id`` and ``data.adj_t`` live on ``device``;
+    node-level tensors of ``data`` are indexed where they live."""
+    device = torch.device(device)
+    part_ids = [int(p) for p in part_ids]
+    batch_id = torch.tensor(part_ids)
+    offset = ptr[batch_id]
+    count = ptr[batch_id + 1] - offset
+    idx = torch.cat([torch.arange(int(ptr[p]), int(ptr[p + 1]), device=device) for p in part_ids])
+    rowptr, col, value = _device_graph(data.adj_t, device)
+    rp32, c32, val, n_id, _ = ops.relabel_one_hop_device(rowptr, col, value, idx,
+                                                         within_batch=in_batch_only)
+    batch_size = idx.numel()
+    adj_t = SparseTensor.from_device_csr(rp32, c32, val, (batch_size, n_id.numel()))
+    out = data.__class__(adj_t=adj_t)
+    for k, v in data:
+        if isinstance(v, Tensor) and v.dim() > 0 and v.size(0) == data.num_nodes:
+            out[k] = v.index_select(0, n_id.to(v.device))
+    return SubData(out, batch_size, n_id, offset, count)
+
+
 class SubgraphLoader(DataLoader):
     r"""A simple subgraph loader that, given a pre-partioned :obj:`data` object,
     generates subgraphs from mini-batches in :obj:`ptr` (including their 1-hop

@@ -7,6 +7,7 @@ reference's native extension are registered under the same names in
 ``torch.ops.torch_geometric_autoscale`` (csrc/async.cpp:44-48, csrc/relabel.cpp:40-42).
 """
 import collections
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -302,6 +303,96 @@ def csr_transpose(rowptr: Tensor, col: Tensor, val: Optional[Tensor], n_rows: in
     t_val = torch.empty(nnz, dtype=torch.float32)
     check(lib().incagg_csr_transpose(_ptr(rowptr), _ptr(col), _ptr(val), n_rows, n_cols,
                                      REDUCE[reduce], t_rowptr.data_ptr(), _ptr(t_col), _ptr(t_val)))
+    return t_rowptr, t_col, t_val
+
+
+# --------------------------------------------------------------------------- batch construction on the GPU
+_build_ws = {}   # device -> {"maps": (a, b), "scratch": uint8 tensor}
+
+
+def _build_workspace(dev, n_nodes: int, scratch_bytes: int):
+    ws = _build_ws.setdefault(dev, {"maps": None, "scratch": None})
+    maps = ws["maps"]
+    if maps is None or maps[0].numel() < n_nodes:
+        # dense id tables, all -1 between calls (every call restores the entries it touched)
+        ws["maps"] = maps = tuple(torch.full((n_nodes,), -1, dtype=torch.int32, device=dev)
+                                  for _ in range(2))
+    if ws["scratch"] is None or ws["scratch"].numel() < scratch_bytes:
+        ws["scratch"] = torch.empty(int(scratch_bytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+    return maps[0], maps[1], ws["scratch"]
+
+
+def relabel_one_hop_device(rowptr: Tensor, col: Tensor, value: Optional[Tensor], idx: Tensor,
+                           within_batch: bool = False, edge_capacity: Optional[int] = None
+                           ) -> Tuple[Tensor, Tensor, Optional[Tensor], Tensor, int]:
+    """The relabelling of csrc/cpu/relabel_cpu.cpp:3-108 (``within_batch``: :111-214) on the
+    GPU, from a device-resident global CSR (int64).  Returns the bipartite device-format batch
+    ``(rowptr int32, col int32, value fp32 | None, n_id int64, distinct ids in idx)``, element
+    for element what the host operators return.  Waits for the stream (sizes come back)."""
+    _need_cuda(rowptr, "rowptr")
+    dev = rowptr.device
+    for t, name in ((rowptr, "rowptr"), (col, "col"), (idx, "idx")):
+        if t.dtype != torch.int64 or t.device != dev or not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous int64 tensor on {dev}")
+    if value is not None and (value.dtype != torch.float32 or value.device != dev
+                              or value.dim() != 1 or not value.is_contiguous()):
+        raise RuntimeError("Value tensor must be a contiguous one-dimensional float32 device tensor")
+    n_nodes, n_idx = rowptr.numel() - 1, idx.numel()
+    L = lib()
+    with torch.cuda.device(dev):
+        stream = _stream_of(dev)
+        if edge_capacity is None:
+            need = 4096 + 16 * (n_idx + 2)
+            _, _, scratch = _build_workspace(dev, n_nodes, need)
+            bound = ctypes.c_int64(0)
+            check(L.incagg_relabel_bound_device(_ptr(rowptr), n_nodes, _ptr(idx), n_idx,
+                                                scratch.data_ptr(), scratch.numel(),
+                                                ctypes.addressof(bound), stream))
+            edge_capacity = int(bound.value)
+        need = L.incagg_relabel_device_scratch_bytes(n_idx, edge_capacity)
+        check(need)
+        map_a, map_b, scratch = _build_workspace(dev, n_nodes, need)
+        node_capacity = n_idx if within_batch else n_idx + edge_capacity
+        out_rowptr = torch.empty(n_idx + 1, dtype=torch.int32, device=dev)
+        out_col = torch.empty(edge_capacity, dtype=torch.int32, device=dev)
+        out_val = None if value is None else torch.empty(edge_capacity, dtype=torch.float32, device=dev)
+        out_n_id = torch.empty(node_capacity, dtype=torch.int64, device=dev)
+        counts = torch.zeros(3, dtype=torch.int64)
+        check(L.incagg_relabel_one_hop_device(
+            _ptr(rowptr), n_nodes, _ptr(col), _ptr(value), _ptr(idx), n_idx,
+            1 if within_batch else 0, edge_capacity, node_capacity, map_a.data_ptr(),
+            map_b.data_ptr(), scratch.data_ptr(), scratch.numel(), out_rowptr.data_ptr(),
+            _ptr(out_col), _ptr(out_val), _ptr(out_n_id), counts.data_ptr(), stream))
+    nnz, n_total, distinct = counts.tolist()
+    return (out_rowptr, out_col[:nnz], None if out_val is None else out_val[:nnz],
+            out_n_id[:n_total], distinct)
+
+
+def csr_transpose_device(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], n_rows: int,
+                         n_cols: int, reduce: str = "sum") -> Tuple[Tensor, Tensor, Tensor]:
+    """:func:`csr_transpose` on the GPU: device-format CSR in, transposed device-format CSR out
+    (same element order as the host routine).  Does not synchronise."""
+    _need_cuda(rowptr32, "rowptr")
+    dev = rowptr32.device
+    if rowptr32.dtype != torch.int32 or col32.dtype != torch.int32:
+        raise TypeError("device CSR must be int32")
+    if rowptr32.numel() != n_rows + 1:
+        raise ValueError("rowptr does not have n_rows + 1 entries")
+    rowptr32, col32 = rowptr32.contiguous(), col32.contiguous()
+    val = None if val is None else val.to(torch.float32).contiguous()
+    nnz = col32.numel()
+    L = lib()
+    need = L.incagg_csr_transpose_device_scratch_bytes(n_cols, nnz)
+    check(need)
+    t_rowptr = torch.empty(n_cols + 1, dtype=torch.int32, device=dev)
+    t_col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    t_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _, _, scratch = _build_workspace(dev, 0, need)
+        check(L.incagg_csr_transpose_device(
+            _ptr(rowptr32) or rowptr32.data_ptr(), _ptr(col32), _ptr(val), n_rows, n_cols, nnz,
+            REDUCE[reduce], scratch.data_ptr(), scratch.numel(), t_rowptr.data_ptr(), _ptr(t_col),
+            _ptr(t_val), _stream_of(dev)))
     return t_rowptr, t_col, t_val
 
 

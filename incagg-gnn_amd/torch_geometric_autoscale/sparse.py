@@ -82,6 +82,27 @@ class SparseTensor:
         self._max_row_nnz: Optional[int] = None
         self.storage = _Storage(self)
 
+    @classmethod
+    def from_device_csr(cls, rowptr32: Tensor, col32: Tensor, value: Optional[Tensor],
+                        sparse_sizes: Tuple[int, int]) -> "SparseTensor":
+        """Wraps a device-format CSR (int32 indices, fp32 values, already on the GPU) as built
+        by the device batch builder: no host copy exists, the transposed CSR and the row
+        orders are derived on the device."""
+        if rowptr32.dtype != torch.int32 or col32.dtype != torch.int32 or not rowptr32.is_cuda:
+            raise TypeError("expected int32 device tensors")
+        out = cls.__new__(cls)
+        out._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        out._device = rowptr32.device
+        out._rowptr_i64 = out._col_i64 = None
+        out._rowptr_i32, out._col_i32 = rowptr32, col32
+        out._value = value
+        out._row = None
+        out._host = None
+        out._transposed = {}
+        out._max_row_nnz = None
+        out.storage = _Storage(out)
+        return out
+
     # ------------------------------------------------------------------ accessors
     def _rowptr64(self) -> Tensor:
         if self._rowptr_i64 is None:
@@ -319,6 +340,19 @@ class SparseTensor:
         """Transposed CSR for dX = A^T dY, with 1/len(row) folded in for 'mean'."""
         key = "mean" if reduce == "mean" else "sum"
         if key not in self._transposed:
+            if self._host is None and self._device.type == "cuda":
+                # built on the device: transposed there too (same element order)
+                t_rowptr, t_col, t_val = ops.csr_transpose_device(
+                    self._rowptr32(), self._col32(), self._value, self._sizes[0], self._sizes[1],
+                    key)
+                cnt = t_rowptr[1:] - t_rowptr[:-1]
+                max_nnz = int(cnt.max()) if cnt.numel() else 0
+                self._transposed[key] = (t_rowptr, t_col, t_val, max_nnz)
+                orders = self.__dict__.setdefault("_orders", {})
+                n_r, n_c = self._sizes
+                for lo, hi in {(0, n_c), (0, min(n_r, n_c))}:
+                    orders[("t", lo, hi)] = ops.degree_order(t_rowptr[lo:hi + 1])
+                return self._transposed[key]
             src = self._host if self._host is not None else self
             rowptr, col, value = src.csr()
             t_rowptr, t_col, t_val = ops.csr_transpose(rowptr, col, value, self._sizes[0],

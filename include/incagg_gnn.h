@@ -255,6 +255,47 @@ int incagg_csr_transpose(const int64_t *rowptr, const int64_t *col, const float 
                          int64_t n_rows, int64_t n_cols, int reduce, int32_t *t_rowptr,
                          int32_t *t_col, float *t_val);
 
+/* ------------------------------------------------------------------ batch build on the device
+ * The same relabelling computed on the GPU from an HBM-resident global CSR, emitting the
+ * device format the aggregation consumes directly (int32 rowptr / col, fp32 values, int64
+ * n_id).  n_id order, local column ids, row pointers and values are identical to
+ * incagg_relabel_one_hop / _within_batch, i.e. to csrc/cpu/relabel_cpu.cpp:3-108,111-214
+ * (first-seen order of a serial scan over the batch's edges, later duplicates of idx win);
+ * the row pointers are always the bipartite ones (n_idx + 1 entries): a caller that wants the
+ * square form pads them with the last value (counts[1] - n_idx times, or counts[2] - n_idx
+ * times for the within-batch variant, as relabel_cpu.cpp:98-106,204-212 does).
+ *
+ *   rowptr[n_nodes+1], col[nnz] device int64; value device fp32[nnz] or NULL; idx device int64
+ *   map_a, map_b: device int32[n_nodes] work tables owned by the caller, every entry -1 on
+ *     entry; they are -1 again when the call returns (map_b may be NULL for within_batch)
+ *   scratch: device bytes, at least incagg_relabel_device_scratch_bytes(n_idx, edge_capacity)
+ *   edge_capacity / node_capacity: sizes of out_col / out_value and of out_n_id;
+ *     incagg_relabel_bound_device gives the exact edge count of the full relabelling (an upper
+ *     bound for within_batch); n_idx + that bound always suffices for the nodes
+ *   counts (HOST int64[3]): edges written, nodes in n_id, distinct ids in idx
+ * Both calls enqueue on `stream` and then wait for it (the sizes come back to the host).
+ */
+int64_t incagg_relabel_device_scratch_bytes(int64_t n_idx, int64_t edge_capacity);
+int incagg_relabel_bound_device(const int64_t *rowptr, int64_t n_nodes, const int64_t *idx,
+                                int64_t n_idx, void *scratch, int64_t scratch_bytes,
+                                int64_t *bound, void *stream);
+int incagg_relabel_one_hop_device(const int64_t *rowptr, int64_t n_nodes, const int64_t *col,
+                                  const float *value, const int64_t *idx, int64_t n_idx,
+                                  int within_batch, int64_t edge_capacity, int64_t node_capacity,
+                                  int32_t *map_a, int32_t *map_b, void *scratch,
+                                  int64_t scratch_bytes, int32_t *out_rowptr, int32_t *out_col,
+                                  float *out_value, int64_t *out_n_id, int64_t *counts,
+                                  void *stream);
+
+/* incagg_csr_transpose on the device (same output, element for element: transposed row c
+ * lists its edges in the order of the original rows).  All pointers are device memory;
+ * scratch >= incagg_csr_transpose_device_scratch_bytes(n_cols, nnz).  Does not synchronise. */
+int64_t incagg_csr_transpose_device_scratch_bytes(int64_t n_cols, int64_t nnz);
+int incagg_csr_transpose_device(const int32_t *rowptr, const int32_t *col, const float *val,
+                                int64_t n_rows, int64_t n_cols, int64_t nnz, int reduce,
+                                void *scratch, int64_t scratch_bytes, int32_t *t_rowptr,
+                                int32_t *t_col, float *t_val, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
