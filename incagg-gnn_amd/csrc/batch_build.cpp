@@ -7,6 +7,7 @@
 // rebuilding a hash table.  Results are defined by the reference's map semantics
 // (csrc/cpu/relabel_cpu.cpp:22-36, 56-69): idx[i] -> i with later duplicates
 // winning, unseen neighbours -> n_idx + first-seen order.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -210,5 +211,110 @@ extern "C" int incagg_csr_transpose(const int64_t *rowptr, const int64_t *col, c
       t_val[pos] = reduce == INCAGG_REDUCE_MEAN ? v * inv : v;
     }
   }
+  return INCAGG_OK;
+}
+
+// ---------------------------------------------------------------- partitioning (host)
+// Stand-in for the METIS call of metis.py:31 (the library is not bundled): equal-sized blocks
+// grown by breadth-first search, then boundary refinement.  The contract downstream only
+// needs a part id per node.
+
+// Fills `num_parts` blocks of ceil(n / num_parts) nodes one after the other by BFS; a new
+// search starts from the next unassigned entry of `seeds` (a permutation of the nodes)
+// whenever the frontier dries up, and afresh for every block.
+extern "C" int incagg_partition_bfs(const int64_t *rowptr, const int64_t *col, int64_t n_nodes,
+                                    int64_t num_parts, const int64_t *seeds, int64_t *cluster) {
+  INCAGG_REQUIRE(rowptr && cluster && n_nodes >= 0 && num_parts >= 1, "bad arguments");
+  INCAGG_REQUIRE(n_nodes == 0 || seeds, "null seeds");
+  const int64_t target = (n_nodes + num_parts - 1) / num_parts;
+  for (int64_t i = 0; i < n_nodes; i++) cluster[i] = -1;
+  std::vector<int64_t> queue;   // FIFO: [head, queue.size())
+  queue.reserve((size_t)std::min<int64_t>(n_nodes, 1 << 20));
+  size_t head = 0;
+  int64_t cursor = 0, part = 0, filled = 0;
+  for (int64_t done = 0; done < n_nodes; done++) {
+    if (head == queue.size()) {
+      queue.clear();
+      head = 0;
+      while (cursor < n_nodes) {
+        const int64_t s = seeds[cursor];
+        if (s < 0 || s >= n_nodes) return fail(INCAGG_E_INDEX, "seed %lld out of range", (long long)s);
+        if (cluster[s] == -1) break;
+        cursor++;
+      }
+      if (cursor >= n_nodes) return fail(INCAGG_E_INVALID, "seeds is not a permutation of the nodes");
+      queue.push_back(seeds[cursor]);
+      cluster[seeds[cursor]] = -2;  // queued
+    }
+    const int64_t v = queue[head++];
+    cluster[v] = part;
+    filled++;
+    if (filled == target && part < num_parts - 1) {
+      for (size_t k = head; k < queue.size(); k++) cluster[queue[k]] = -1;  // un-queue
+      queue.clear();
+      head = 0;
+      part++;
+      filled = 0;
+      continue;
+    }
+    for (int64_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
+      const int64_t w = col[e];
+      if (w < 0 || w >= n_nodes) return fail(INCAGG_E_INDEX, "column id %lld out of range", (long long)w);
+      if (cluster[w] == -1) {
+        cluster[w] = -2;
+        queue.push_back(w);
+      }
+    }
+  }
+  return INCAGG_OK;
+}
+
+// Boundary refinement: in sweeps over the nodes, a node moves to the part that holds most of
+// its neighbours when that strictly lowers the number of cut edges and the receiving part
+// stays within `max_part_size`.  Returns the number of moves made in `moves` (may be NULL).
+extern "C" int incagg_partition_refine(const int64_t *rowptr, const int64_t *col, int64_t n_nodes,
+                                       int64_t num_parts, int64_t max_part_size, int64_t sweeps,
+                                       int64_t *cluster, int64_t *moves) {
+  INCAGG_REQUIRE(rowptr && cluster && n_nodes >= 0 && num_parts >= 1 && sweeps >= 0, "bad arguments");
+  std::vector<int64_t> size((size_t)num_parts, 0);
+  for (int64_t v = 0; v < n_nodes; v++) {
+    if (cluster[v] < 0 || cluster[v] >= num_parts)
+      return fail(INCAGG_E_INDEX, "part id %lld of node %lld out of range", (long long)cluster[v], (long long)v);
+    size[(size_t)cluster[v]]++;
+  }
+  std::vector<int64_t> tally((size_t)num_parts, 0), touched;
+  int64_t total = 0;
+  for (int64_t s = 0; s < sweeps; s++) {
+    int64_t moved = 0;
+    for (int64_t v = 0; v < n_nodes; v++) {
+      touched.clear();
+      for (int64_t e = rowptr[v]; e < rowptr[v + 1]; e++) {
+        const int64_t w = col[e];
+        if (w < 0 || w >= n_nodes) return fail(INCAGG_E_INDEX, "column id %lld out of range", (long long)w);
+        if (w == v) continue;
+        const int64_t p = cluster[w];
+        if (tally[(size_t)p]++ == 0) touched.push_back(p);
+      }
+      const int64_t home = cluster[v];
+      int64_t best = home, best_cnt = tally[(size_t)home];
+      for (int64_t p : touched)
+        if (p != home && size[(size_t)p] < max_part_size &&
+            (tally[(size_t)p] > best_cnt || (tally[(size_t)p] == best_cnt && best != home && p < best))) {
+          best = p;
+          best_cnt = tally[(size_t)p];
+        }
+      for (int64_t p : touched) tally[(size_t)p] = 0;
+      tally[(size_t)home] = 0;
+      if (best != home && size[(size_t)home] > 1) {
+        cluster[v] = best;
+        size[(size_t)home]--;
+        size[(size_t)best]++;
+        moved++;
+      }
+    }
+    total += moved;
+    if (moved == 0) break;
+  }
+  if (moves) *moves = total;
   return INCAGG_OK;
 }

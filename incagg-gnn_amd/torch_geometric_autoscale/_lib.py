@@ -41,6 +41,8 @@ SIGNATURES = {
     "incagg_relabel_one_hop_within_batch": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _int, _vp,
                                                    _vp, _vp, _vp, _vp]),
     "incagg_csr_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+    "incagg_partition_bfs": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "incagg_partition_refine": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "incagg_relabel_device_scratch_bytes": (_i64, [_i64, _i64]),
     "incagg_relabel_bound_device": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "incagg_relabel_one_hop_device": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp,

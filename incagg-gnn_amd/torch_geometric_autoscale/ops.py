@@ -306,6 +306,34 @@ def csr_transpose(rowptr: Tensor, col: Tensor, val: Optional[Tensor], n_rows: in
     return t_rowptr, t_col, t_val
 
 
+def partition_bfs(rowptr: Tensor, col: Tensor, num_parts: int, seeds: Tensor) -> Tensor:
+    """Part id per node by breadth-first block growing (host; see include/incagg_gnn.h)."""
+    rowptr, col = _host_i64(rowptr, "rowptr"), _host_i64(col, "col")
+    seeds = _host_i64(seeds, "seeds")
+    n = rowptr.numel() - 1
+    if seeds.numel() != n:
+        raise ValueError("seeds must list every node once")
+    cluster = torch.empty(n, dtype=torch.int64)
+    check(lib().incagg_partition_bfs(_ptr(rowptr) or rowptr.data_ptr(), _ptr(col), n,
+                                     int(num_parts), _ptr(seeds), _ptr(cluster)))
+    return cluster
+
+
+def partition_refine(rowptr: Tensor, col: Tensor, num_parts: int, cluster: Tensor,
+                     max_part_size: int, sweeps: int = 4) -> Tuple[Tensor, int]:
+    """Boundary refinement of a partition (host); returns the new part ids and the moves made."""
+    rowptr, col = _host_i64(rowptr, "rowptr"), _host_i64(col, "col")
+    cluster = _host_i64(cluster, "cluster").clone()
+    n = rowptr.numel() - 1
+    if cluster.numel() != n:
+        raise ValueError("cluster must have one entry per node")
+    moves = ctypes.c_int64(0)
+    check(lib().incagg_partition_refine(_ptr(rowptr) or rowptr.data_ptr(), _ptr(col), n,
+                                        int(num_parts), int(max_part_size), int(sweeps),
+                                        _ptr(cluster), ctypes.addressof(moves)))
+    return cluster, int(moves.value)
+
+
 # --------------------------------------------------------------------------- batch construction on the GPU
 _build_ws = {}   # device -> {"maps": (a, b), "scratch": uint8 tensor}
 

@@ -255,6 +255,21 @@ int incagg_csr_transpose(const int64_t *rowptr, const int64_t *col, const float 
                          int64_t n_rows, int64_t n_cols, int reduce, int32_t *t_rowptr,
                          int32_t *t_col, float *t_val);
 
+/* ------------------------------------------------------------------ partitioning (host)
+ * Stand-in for the METIS call of metis.py:31 (`torch.ops.torch_sparse.partition`, a library
+ * that is not bundled): a part id per node, from which metis.py:32-33 derives (perm, ptr).
+ * incagg_partition_bfs grows num_parts blocks of ceil(n / num_parts) nodes by breadth-first
+ * search, restarting from the next unassigned entry of `seeds` (host int64[n_nodes], a
+ * permutation); incagg_partition_refine then moves boundary nodes to the part holding most
+ * of their neighbours while that lowers the edge cut and no part exceeds max_part_size.
+ * All arrays are host int64; the CSR is expected to be symmetric.
+ */
+int incagg_partition_bfs(const int64_t *rowptr, const int64_t *col, int64_t n_nodes,
+                         int64_t num_parts, const int64_t *seeds, int64_t *cluster);
+int incagg_partition_refine(const int64_t *rowptr, const int64_t *col, int64_t n_nodes,
+                            int64_t num_parts, int64_t max_part_size, int64_t sweeps,
+                            int64_t *cluster, int64_t *moves);
+
 /* ------------------------------------------------------------------ batch build on the device
  * The same relabelling computed on the GPU from an HBM-resident global CSR, emitting the
  * device format the aggregation consumes directly (int32 rowptr / col, fp32 values, int64
