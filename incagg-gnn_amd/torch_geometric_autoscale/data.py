@@ -151,12 +151,42 @@ def gcn_norm(adj_t: SparseTensor, add_self_loops: bool = False) -> SparseTensor:
     return adj_t.set_value(dis[row] * value * dis[col])
 
 
+def load_npz_dataset(path: str):
+    """A graph stored as plain arrays: ``rowptr``, ``col`` (int64 CSR of the symmetric
+    adjacency), ``x`` [N, F] float32, ``y`` [N] int64 (or [N, C] float for multi-label) and
+    boolean ``train_mask`` / ``val_mask`` / ``test_mask``.  Nothing in the file is executed."""
+    import numpy as np
+    with np.load(path, allow_pickle=False) as z:
+        arrays = {k: torch.from_numpy(z[k]) for k in z.files}
+    for k in ("rowptr", "col", "x", "y"):
+        if k not in arrays:
+            raise ValueError(f"{path}: array '{k}' missing")
+    n = arrays["rowptr"].numel() - 1
+    adj_t = SparseTensor(rowptr=arrays["rowptr"].to(torch.int64), col=arrays["col"].to(torch.int64),
+                         sparse_sizes=(n, n), is_sorted=True)
+    data = Data(adj_t=adj_t, num_nodes=n, x=arrays["x"].to(torch.float32), y=arrays["y"])
+    for k in ("train_mask", "val_mask", "test_mask"):
+        if k in arrays:
+            data[k] = arrays[k].to(torch.bool)
+    y = data.y
+    n_cls = int(y.max()) + 1 if y.dim() == 1 else y.size(1)
+    return data, data.x.size(1), n_cls
+
+
 def get_data(root: Optional[str], name: str, num_parts: int = 16, scale: float = 1.0,
              cross_fraction: float = 0.15, seed: int = 0, features: bool = True, device="cpu",
-             keep_on_device: bool = False):
-    """``(data, in_channels, out_channels)`` like data.py:118-145, on a synthetic graph with
-    the named dataset's statistics (``scale`` shrinks nodes and edges together).
-    ``data.ptr`` holds the planted partition boundaries."""
+             keep_on_device: bool = False, planted_labels: bool = False):
+    """``(data, in_channels, out_channels)`` like data.py:118-145.  If ``root/<name>.npz``
+    exists it is loaded (:func:`load_npz_dataset`; datasets are never downloaded); otherwise
+    a synthetic graph with the named dataset's statistics is generated (``scale`` shrinks
+    nodes and edges together) and ``data.ptr`` holds the planted partition boundaries.
+    ``planted_labels``: labels follow the planted communities and the features carry a noisy
+    class signal, so that training has something to learn (default: random labels)."""
+    import os
+    if root is not None:
+        path = os.path.join(root, f"{name}.npz")
+        if os.path.isfile(path):
+            return load_npz_dataset(path)
     key = name.lower().replace('ogbn-', '')
     if key not in DATASET_STATS:
         raise NotImplementedError(f"unknown dataset '{name}'")
@@ -169,6 +199,12 @@ def get_data(root: Optional[str], name: str, num_parts: int = 16, scale: float =
     if features:
         data.x = torch.randn(n, f_in, generator=g)
     data.y = torch.randint(0, n_cls, (n,), generator=g)
+    if planted_labels:
+        part = torch.repeat_interleave(torch.arange(num_parts), ptr[1:] - ptr[:-1])
+        data.y = part % n_cls
+        if features:
+            centres = torch.randn(n_cls, f_in, generator=g)
+            data.x = data.x + 0.5 * centres[data.y]
     split = torch.rand(n, generator=g)
     data.train_mask = split < 0.6
     data.val_mask = (split >= 0.6) & (split < 0.8)

@@ -56,11 +56,19 @@ class ScalableGNN(torch.nn.Module):
         self.pool_size = num_layers - 1 if pool_size is None else pool_size
         self.buffer_size = buffer_size
 
+        # Layer 0 of some models aggregates the raw features, which may be wider than the hidden
+        # width (the reference only handles the narrower case, models/gcn.py:355-365).  Device
+        # tables of layer 0 are then made wide enough; host tables keep one width for all
+        # layers because the staging slots are shared between them.
+        w0 = hidden_channels
+        if self.raw_input_layer and in_channels is not None and device is not None:
+            w0 = max(hidden_channels, int(in_channels))
+        widths = [w0] + [hidden_channels] * (num_layers - 1)
         self.histories = torch.nn.ModuleList(
-            [History(num_nodes, hidden_channels, device) for _ in range(num_layers)])
+            [History(num_nodes, w, device) for w in widths])
         self.pool: Optional[AsyncIOPool] = None
         self.histories_ag = torch.nn.ModuleList(
-            [History(num_nodes, hidden_channels, device) for _ in range(num_layers)])
+            [History(num_nodes, w, device) for w in widths])
         self.pool_ag: Optional[AsyncIOPool] = None
 
         self._async = False
@@ -120,6 +128,7 @@ class ScalableGNN(torch.nn.Module):
 
     # ------------------------------------------------------------------ hooks
     agg_reduce = "sum"
+    raw_input_layer = False   # layer 0 aggregates the raw features (no embedding in front)
 
     def _embed(self, x: Tensor, state: Dict[str, Any], batch_size: int) -> Tensor:
         """Layer-0 input rows from raw features (may fill ``state``)."""
@@ -519,6 +528,11 @@ class ScalableGNN(torch.nn.Module):
             adj_t = data.adj_t.to(self.device)
             x = self._embed(data.x.to(self.device), state, batch_size)
             if with_aggregates:
+                if x.size(1) > self.histories[0].embedding_dim:
+                    raise ValueError(
+                        f"layer-0 rows are {x.size(1)} wide but the History tables only "
+                        f"{self.histories[0].embedding_dim}: keep the tables on the GPU "
+                        "(device=...) or choose hidden_channels >= in_channels")
                 self._push_rows(self.histories[0].emb, x[:batch_size], self._local(offset), count,
                                 pool)
             run_layer(0, x, adj_t, batch_size, offset, count, state)

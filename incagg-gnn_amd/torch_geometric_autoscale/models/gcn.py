@@ -10,6 +10,8 @@ from .base import ScalableGNN
 
 
 class GCN(ScalableGNN):
+    raw_input_layer = True
+
     def __init__(self, num_nodes: int, in_channels, hidden_channels: int, out_channels: int,
                  num_layers: int, dropout: float = 0.0, drop_input: bool = True,
                  batch_norm: bool = False, residual: bool = False, linear: bool = False,
