@@ -53,7 +53,8 @@ def dropout(adj_t: SparseTensor, p: float, training: bool = True) -> SparseTenso
     """Random edge dropout on an adjacency (utils.py:62-73)."""
     if not training or p == 0.:
         return adj_t
-    if adj_t.has_value():
-        raise NotImplementedError("edge dropout on a weighted adjacency")
+    if adj_t.has_value():   # weights are dropped (and the survivors rescaled), structure kept
+        value = torch.nn.functional.dropout(adj_t.storage.value(), p=p)
+        return adj_t.set_value(value, layout='coo')
     mask = torch.rand(adj_t.nnz(), device=adj_t.device()) > p
     return adj_t.masked_select_nnz(mask, layout='coo')

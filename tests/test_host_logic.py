@@ -144,3 +144,38 @@ def test_history_interface_on_host():
     assert float(h.pull().sum()) == 30
     with pytest.raises(NotImplementedError):
         h(x)
+
+
+def test_neighbor_sampling_and_edge_dropout():
+    """Per-row neighbour sampling of the train loader (loader.py:32-93, :217-246) and edge
+    dropout (utils.py:62-73)."""
+    import torch_geometric_autoscale as tga
+    from torch_geometric_autoscale.loader import sample_neighbors
+    adj, ptr = tga.synthetic_graph(600, 600 * 12, 4, seed=2)
+    rowptr, col, _ = adj.csr()
+    torch.manual_seed(0)
+    out, _ = sample_neighbors(adj, 5)
+    rp2, col2, _ = out.csr()
+    deg, deg2 = rowptr[1:] - rowptr[:-1], rp2[1:] - rp2[:-1]
+    assert torch.equal(deg2, torch.clamp(deg, max=5))
+    for r in (0, 17, 300, 599):   # survivors are a subset of the row, original order kept
+        full = col[rowptr[r]:rowptr[r + 1]].tolist()
+        kept = col2[rp2[r]:rp2[r + 1]].tolist()
+        assert kept == sorted(kept) and set(kept) <= set(full)
+    assert sample_neighbors(adj, -1)[0] is adj
+    # the train loader with a neighbour budget: batches keep their node lists, rows are capped
+    data = tga.Data(adj_t=adj, num_nodes=600, x=torch.randn(600, 4))
+    loader = tga.SubgraphLoader(data, ptr, batch_size=2, shuffle=False, type='train',
+                                num_neighbors=3, log=False)
+    for sub in loader:
+        rp, c, _ = sub.data.adj_t.csr()
+        assert int((rp[1:] - rp[:-1]).max()) <= 3
+        assert sub.data.x.size(0) == sub.n_id.numel() and int(c.max()) < sub.n_id.numel()
+    # edge dropout: structure thinned without weights, weights dropped and rescaled with them
+    torch.manual_seed(1)
+    thin = tga.dropout(adj, 0.5)
+    assert 0.3 * adj.nnz() < thin.nnz() < 0.7 * adj.nnz()
+    assert tga.dropout(adj, 0.5, training=False) is adj and tga.dropout(adj, 0.0) is adj
+    weighted = adj.fill_value(1.0)
+    w = tga.dropout(weighted, 0.5).storage.value()
+    assert w.numel() == adj.nnz() and set(w.unique().tolist()) == {0.0, 2.0}
