@@ -239,7 +239,7 @@ def main():
         for tables in (model.histories, model.histories_ag):   # non-trivial table contents
             for h in tables:
                 h.emb.normal_(0, 0.1, generator=g)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # one launch per step
     crit = torch.nn.CrossEntropyLoss()
     model.train()
     setup_s = time.perf_counter() - t_setup

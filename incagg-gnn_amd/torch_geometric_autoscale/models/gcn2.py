@@ -5,7 +5,9 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import BatchNorm1d, ModuleList
 
-from ..nn import GCN2Conv, RowsLinear
+import torch
+
+from ..nn import GCN2Conv, RowsLinear, embed_relu, gcn2_batched_terms
 from .base import ScalableGNN
 
 
@@ -55,8 +57,13 @@ class GCN2(ScalableGNN):
     def _embed(self, x: Tensor, state: Dict[str, Any], batch_size: int) -> Tensor:
         if self.drop_input:
             x = F.dropout(x, p=self.dropout, training=self.training)
-        x = x_0 = self.lins[0](x).relu_()
-        state['x_0'] = x_0[:batch_size]
+        x, state['x_0'] = embed_relu(self.lins[0], x, batch_size)
+        # Training steps (one batch, all layers back to back): the x_0 terms of every layer in
+        # one GEMM.  Not in the sweeps, where the per-batch state outlives the layer loop and
+        # the terms of all batches would have to stay resident.
+        if (self.convs[0].weight2 is not None and torch.is_grad_enabled()
+                and len({conv.alpha for conv in self.convs}) == 1):
+            state['w1f'], state['x0_terms'] = gcn2_batched_terms(self.convs, state['x_0'])
         return F.dropout(x, p=self.dropout, training=self.training)
 
     def _post(self, layer: int, h: Tensor, x: Tensor) -> Tensor:
@@ -72,7 +79,12 @@ class GCN2(ScalableGNN):
 
     def _update(self, layer: int, agg: Tensor, x: Tensor, state: Dict[str, Any],
                 pre: bool = False) -> Tensor:
-        return self._post(layer, self.convs[layer].forward_after_propagate(agg, state['x_0']), x)
+        if 'x0_terms' in state:
+            h = self.convs[layer].forward_after_propagate(
+                agg, state['x_0'], state['w1f'][layer], state['x0_terms'][layer])
+        else:
+            h = self.convs[layer].forward_after_propagate(agg, state['x_0'])
+        return self._post(layer, h, x)
 
     def _mix(self, layer: int, state: Dict[str, Any], batch_size: int):
         conv = self.convs[layer]

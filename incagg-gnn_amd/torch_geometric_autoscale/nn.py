@@ -22,10 +22,12 @@ from .sparse import SparseTensor
 def _tn_product(a: Tensor, b: Tensor) -> Tensor:
     """``a^T @ b`` for tall operands ([rows, m], [rows, n], rows >> m, n): the shape of every
     weight gradient here.  A [m, n] output gives a GEMM only a handful of tiles while the
-    reduction runs over 10^4..10^5 rows, so the rows are cut into 8 slabs that run as one
-    batched product (8x the tiles) and are summed afterwards."""
+    reduction runs over 10^4..10^5 rows, so the rows are cut into slabs that run as one
+    batched product (8x / 32x the tiles) and are summed afterwards.  Measured on MI355X:
+    16k rows x 256 x 256: 49 us with 8 slabs vs 107 us as one GEMM; 128k rows x 256 x 100:
+    77 us with 32 slabs, 123 us with 8, 376 us as one GEMM."""
     rows = a.size(0)
-    slabs = 8
+    slabs = 8 if rows < 65536 else 32
     if rows < 4096 or a.dim() != 2:
         return a.t() @ b
     k = (rows // slabs) * slabs
@@ -57,12 +59,50 @@ class _RowsLinear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _EmbedRelu(torch.autograd.Function):
+    """``x_0 = relu(x W^T + b)`` returned twice: all rows (the input of the first aggregation)
+    and the first ``n_batch`` rows (the ``x_0`` term of every GCNII layer, models/gcn2.py:46-48).
+    With the slice taken inside, the backward pass adds the two incoming gradients on the
+    batch rows only, instead of materialising a zero-padded full-size copy of the small one and
+    adding two full-size matrices."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, n_batch):
+        h = (x @ weight.t() if bias is None else torch.addmm(bias, x, weight.t())).relu_()
+        ctx.save_for_backward(x, weight, h)
+        ctx.has_bias, ctx.n_batch = bias is not None, n_batch
+        return h, h[:n_batch]
+
+    @staticmethod
+    def backward(ctx, d_all, d_batch):
+        x, weight, h = ctx.saved_tensors
+        nb = ctx.n_batch
+        if d_all is None:
+            g = torch.zeros_like(h)
+        else:
+            g = torch.ops.aten.threshold_backward(d_all.contiguous(), h, 0)   # new tensor
+        if d_batch is not None:
+            g[:nb] += torch.ops.aten.threshold_backward(d_batch.contiguous(), h[:nb], 0)
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = _tn_product(g, x) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def embed_relu(lin: Linear, x: Tensor, n_batch: int):
+    """``(relu(lin(x)), relu(lin(x))[:n_batch])`` through :class:`_EmbedRelu`."""
+    return _EmbedRelu.apply(x, lin.weight, lin.bias, n_batch)
+
+
 class _TwoTermUpdate(torch.autograd.Function):
     """``h @ W1 + x0 @ W2`` (``x0`` / ``W2`` optional) with split-row weight gradients."""
 
     @staticmethod
-    def forward(ctx, h, w1, x0, w2):
+    def forward(ctx, h, w1, x0, w2, term=None):
         ctx.save_for_backward(h, w1, x0, w2)
+        ctx.has_term = term is not None
+        if term is not None:        # the second summand arrives ready-made
+            return torch.addmm(term, h, w1)
         if x0 is None:
             return h @ w1
         return torch.addmm(x0 @ w2, h, w1)
@@ -77,7 +117,8 @@ class _TwoTermUpdate(torch.autograd.Function):
         if x0 is not None:
             dx0 = dy @ w2.t() if ctx.needs_input_grad[2] else None
             dw2 = _tn_product(x0, dy) if ctx.needs_input_grad[3] else None
-        return dh, dw1, dx0, dw2
+        dterm = dy if ctx.has_term and ctx.needs_input_grad[4] else None
+        return dh, dw1, dx0, dw2, dterm
 
 
 class RowsLinear(Linear):
@@ -167,9 +208,14 @@ class GCN2Conv(torch.nn.Module):
             eye = self._eye = torch.eye(self.channels, device=weight.device, dtype=weight.dtype)
         return torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta)
 
-    def forward_after_propagate(self, h: Tensor, x_0: Tensor) -> Tensor:
-        """Everything after the propagation, given ``h = A x`` (models/gcn2.py:257,306)."""
+    def forward_after_propagate(self, h: Tensor, x_0: Tensor, w1_folded: Optional[Tensor] = None,
+                                x0_term: Optional[Tensor] = None) -> Tensor:
+        """Everything after the propagation, given ``h = A x`` (models/gcn2.py:257,306).
+        ``w1_folded`` / ``x0_term``: this layer's slice of :func:`gcn2_batched_terms`, computed
+        for all layers at once by the caller."""
         b = h.size(0)
+        if x0_term is not None:
+            return _TwoTermUpdate.apply(h, w1_folded, None, None, x0_term)
         x_0 = x_0 if x_0.size(0) == b else x_0[:b]
         if self.weight2 is None:
             p = torch.add(h * (1 - self.alpha), x_0, alpha=self.alpha)
@@ -192,6 +238,26 @@ class GCN2Conv(torch.nn.Module):
             return self.update_mixed(spmm(adj_t, x, scale=1 - self.alpha, add=x_0[:b],
                                           add_scale=self.alpha))
         return self.forward_after_propagate(spmm(adj_t, x), x_0)
+
+
+def gcn2_batched_terms(convs, x_0: Tensor):
+    """For GCNII layers with separate weights: the folded first weights of ALL layers,
+    ``[L, C, C]``, and the ``x_0`` summands of all layers, a list of L ``[rows, C]`` matrices
+    cut from ONE ``[rows, C] x [C, L*C]`` product -- ``x_0`` is the same matrix in every layer
+    (models/gcn2.py:46-48), so its L small GEMMs (and, in the backward pass, L weight-gradient
+    GEMMs and L accumulations into ``d x_0``) collapse into one wide GEMM each."""
+    n_layers, c = len(convs), convs[0].channels
+    dev, dt = x_0.device, x_0.dtype
+    beta = torch.tensor([conv.beta for conv in convs], device=dev, dtype=dt).view(-1, 1, 1)
+    alpha = convs[0].alpha
+    eye = torch.eye(c, device=dev, dtype=dt)
+    w1 = torch.stack([conv.weight1 for conv in convs])
+    w2 = torch.stack([conv.weight2 for conv in convs])
+    w1f = (1.0 - alpha) * (beta * w1 + (1.0 - beta) * eye)
+    w2f = alpha * (beta * w2 + (1.0 - beta) * eye)
+    w2cat = w2f.permute(1, 0, 2).reshape(c, n_layers * c)
+    terms = (x_0 @ w2cat).view(x_0.size(0), n_layers, c).unbind(1)
+    return w1f, terms
 
 
 class SAGEConv(torch.nn.Module):

@@ -205,7 +205,7 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
              weight_decay=params.get("reg_weight_decay", 0.0)),
         dict(params=model.nonreg_modules.parameters(),
              weight_decay=params.get("nonreg_weight_decay", 0.0)),
-    ], lr=params.get("lr", 0.01))
+    ], lr=params.get("lr", 0.01), fused=device.type == "cuda")
     use_agg = bool(conf["use_aggregation"])
 
     def refresh():

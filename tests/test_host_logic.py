@@ -179,3 +179,36 @@ def test_neighbor_sampling_and_edge_dropout():
     weighted = adj.fill_value(1.0)
     w = tga.dropout(weighted, 0.5).storage.value()
     assert w.numel() == adj.nnz() and set(w.unique().tolist()) == {0.0, 2.0}
+
+
+def test_batched_gcn2_terms_and_fused_embed_have_the_plain_gradients():
+    """The all-layers-at-once x_0 GEMM and the fused embed/relu backward are re-arrangements:
+    outputs and gradients must equal the layer-by-layer composition."""
+    from torch_geometric_autoscale.nn import GCN2Conv, RowsLinear, embed_relu, gcn2_batched_terms
+    torch.manual_seed(0)
+    rows, b, f_in, c, n_layers = 50, 30, 7, 16, 3
+    lin = RowsLinear(f_in, c).double()
+    convs = [GCN2Conv(c, alpha=0.1, theta=0.5, layer=i + 1, shared_weights=False).double()
+             for i in range(n_layers)]
+    x = torch.randn(rows, f_in, dtype=torch.float64)
+    aggs = [torch.randn(b, c, dtype=torch.float64) for _ in range(n_layers)]
+    params = list(lin.parameters()) + [p for conv in convs for p in conv.parameters()]
+
+    def run(fast):
+        if fast:
+            full, x0 = embed_relu(lin, x, b)
+            w1f, terms = gcn2_batched_terms(convs, x0)
+            outs = [conv.forward_after_propagate(a, x0, w1f[i], terms[i])
+                    for i, (conv, a) in enumerate(zip(convs, aggs))]
+        else:
+            full = lin(x).relu()
+            x0 = full[:b]
+            outs = [conv.forward_after_propagate(a, x0) for conv, a in zip(convs, aggs)]
+        loss = sum((o * o).sum() for o in outs) + (full * torch.arange(c, dtype=torch.float64)).sum()
+        grads = torch.autograd.grad(loss, params)
+        return outs, grads
+
+    outs_f, grads_f = run(True)
+    outs_p, grads_p = run(False)
+    for a, b_ in zip(outs_f + list(grads_f), outs_p + list(grads_p)):
+        assert torch.allclose(a, b_, rtol=1e-10, atol=1e-10)
