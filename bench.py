@@ -154,6 +154,11 @@ def cpu_baseline(batches, layers, width, seconds):
 
 def main():
     args = parse()
+    # Only the JSON line may reach stdout: communication libraries print banners there.
+    # Everything else this process (and its native libraries) writes goes to stderr.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,6 +264,23 @@ def main():
         opt.step()
         return bt["edges"]
 
+    # Untimed priming before the W warmup steps: every prepared batch once (batches differ in
+    # shape: GEMM code objects and allocator blocks for all shapes exist afterwards), and at
+    # least ~1.5 s of sustained work.  On a freshly started machine the first process sees a
+    # one-off stall of ~90 ms roughly 0.7 s into sustained GPU load (measured on three fresh
+    # boxes; absent from every later process), which would otherwise land inside the K steps.
+    t_prime = time.perf_counter()
+    prime_seconds = float(os.environ.get("BENCH_PRIME_SECONDS", "1.5"))
+    while True:
+        for i in range(len(batches)):
+            step(i)
+        torch.cuda.synchronize()
+        done = torch.tensor([time.perf_counter() - t_prime >= prime_seconds], device=dev,
+                            dtype=torch.int32)
+        if sharded:                      # every rank runs the same number of passes
+            dist.broadcast(done, 0)
+        if int(done):
+            break
     for i in range(args.warmup):
         step(i)
     if sharded:
@@ -267,14 +289,19 @@ def main():
     clock.enabled = True
     t0 = time.perf_counter()
     edges = 0
+    host_marks = [t0]
     for i in range(args.steps):
         edges += step(args.warmup + i)
+        host_marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     clock.enabled = False
+    if os.environ.get("BENCH_TRACE"):   # host-side enqueue time of every step
+        print("enqueue ms/step:", " ".join(f"{(b - a) * 1e3:.2f}" for a, b in
+                                             zip(host_marks, host_marks[1:])), file=sys.stderr)
     _lib.check_device_errors()
 
     tot = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
@@ -357,7 +384,7 @@ def main():
                 host.append((rp.numpy(), c.numpy(), v.numpy().astype(np.float32),
                              int(b_["n_id"].numel())))
             line["cpu_baseline"] = cpu_baseline(host, args.layers, args.hidden, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if sharded:
         dist.destroy_process_group()
 
