@@ -662,7 +662,11 @@ __global__ __launch_bounds__(256) void rows_sub_kernel(const float *a, long long
 // ---------------------------------------------------------------- host side
 struct HubQueue {
   int2 *entries = nullptr;
-  int *counters = nullptr;  // two words used alternately; the idle one is zero
+  // words 0 / 1 are used alternately by eager calls (the idle one is zero: each slice kernel
+  // clears the word of the next call); word 2 belongs to calls recorded into a HIP graph,
+  // which clear it with a recorded memset instead -- a replayed call runs none of this host
+  // code, so it cannot take part in the alternation; word 3 is a scratch target.
+  int *counters = nullptr;
   int parity = 0;
 };
 
@@ -677,9 +681,17 @@ static int hub_queue_for(hipStream_t stream, HubQueue **out) {
   std::lock_guard<std::mutex> lock(s_queue_mutex);
   HubQueue &q = s_queues[{dev, stream}];
   if (!q.entries) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (cap != hipStreamCaptureStatusNone) {
+      s_queues.erase({dev, stream});
+      return fail(INCAGG_E_INVALID,
+                  "the slice queue of this stream does not exist yet and cannot be allocated while "
+                  "the stream is being captured: run one aggregation on the stream first");
+    }
     INCAGG_HIP_TRY(hipMalloc(&q.entries, sizeof(int2) * (size_t)kQueueCap));
-    hipError_t e = hipMalloc(&q.counters, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(q.counters, 0, 2 * sizeof(int));
+    hipError_t e = hipMalloc(&q.counters, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(q.counters, 0, 4 * sizeof(int));
     if (e != hipSuccess) {
       (void)hipFree(q.entries);
       q.entries = nullptr;
@@ -687,6 +699,27 @@ static int hub_queue_for(hipStream_t stream, HubQueue **out) {
     }
   }
   *out = &q;
+  return INCAGG_OK;
+}
+
+// Points the launch at the queue's counters.  `advance` is set when the caller has to flip the
+// parity after its two launches (eager call); a call that is being captured gets its own word,
+// cleared by a memset that is recorded in front of it.
+static int bind_queue(SpmmArgs &a, HubQueue *q, hipStream_t stream, bool *advance) {
+  a.queue = q->entries;
+  a.q_cap = kQueueCap;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  INCAGG_HIP_TRY(hipStreamIsCapturing(stream, &cap));
+  if (cap == hipStreamCaptureStatusNone) {
+    a.q_count = q->counters + q->parity;
+    a.q_count_next = q->counters + (q->parity ^ 1);
+    *advance = true;
+  } else {
+    INCAGG_HIP_TRY(hipMemsetAsync(q->counters + 2, 0, sizeof(int), stream));
+    a.q_count = q->counters + 2;
+    a.q_count_next = q->counters + 3;
+    *advance = false;
+  }
   return INCAGG_OK;
 }
 
@@ -722,14 +755,13 @@ static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
   a.hub_slice = hub_slice;
   const bool may_have_hubs = max_row_nnz < 0 || max_row_nnz > hub_threshold;
   HubQueue *q = nullptr;
+  bool advance = false;
   if (may_have_hubs) {
     int rc = hub_queue_for(stream, &q);
     if (rc) return rc;
     a.hub_threshold = hub_threshold;
-    a.queue = q->entries;
-    a.q_count = q->counters + q->parity;
-    a.q_count_next = q->counters + (q->parity ^ 1);
-    a.q_cap = kQueueCap;
+    rc = bind_queue(a, q, stream, &advance);
+    if (rc) return rc;
   } else {
     a.hub_threshold = INT_MAX;
     a.queue = nullptr;
@@ -744,7 +776,7 @@ static int launch_spmm(SpmmArgs &a, long long max_row_nnz, hipStream_t stream) {
     hipLaunchKernelGGL((spmm_hub_kernel<VEC, CH, INCAGG>), dim3(hub_blocks),
                        dim3(kWave * kWavesPerBlock), 0, stream, a);
     INCAGG_HIP_TRY(hipGetLastError());
-    q->parity ^= 1;
+    if (advance) q->parity ^= 1;
   }
   return INCAGG_OK;
 }
@@ -766,14 +798,13 @@ static int launch_sliced(SpmmArgs &a, long long max_row_nnz, bool grouped, hipSt
   a.hub_slice = hub_slice;
   const bool may_have_hubs = max_row_nnz < 0 || max_row_nnz > hub_threshold;
   HubQueue *q = nullptr;
+  bool advance = false;
   if (may_have_hubs) {
     int rc = hub_queue_for(stream, &q);
     if (rc) return rc;
     a.hub_threshold = hub_threshold;
-    a.queue = q->entries;
-    a.q_count = q->counters + q->parity;
-    a.q_count_next = q->counters + (q->parity ^ 1);
-    a.q_cap = kQueueCap;
+    rc = bind_queue(a, q, stream, &advance);
+    if (rc) return rc;
   } else {
     a.hub_threshold = INT_MAX;
   }
@@ -805,7 +836,7 @@ static int launch_sliced(SpmmArgs &a, long long max_row_nnz, bool grouped, hipSt
       hipLaunchKernelGGL((spmm_sliced_hub_kernel<INCAGG, false>), hub_grid, block, 0, stream, a,
                          n_slices);
     INCAGG_HIP_TRY(hipGetLastError());
-    q->parity ^= 1;
+    if (advance) q->parity ^= 1;
   }
   return INCAGG_OK;
 }

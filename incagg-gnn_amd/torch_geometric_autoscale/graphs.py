@@ -1,0 +1,47 @@
+"""HIP-graph capture of whole training steps.
+
+A history-based training step is ~180 kernel launches (aggregations, History pushes, GEMMs,
+element-wise glue, the optimizer) issued from Python; on MI355X the launches of one step take
+the host about as long as the GPU needs to run them.  A step over a given partition batch is
+the same launch sequence every epoch -- same shapes, same addresses once its inputs are kept
+in static tensors -- so it is recorded once into a HIP graph and replayed with a single call.
+
+All graphs of a :class:`StepGraphs` share one memory pool and one capture stream (they are
+replayed one after the other, never concurrently).  The aggregation library needs its
+per-stream slice queue to exist before a stream is captured; :meth:`StepGraphs.warm` runs the
+step eagerly on the capture stream first, which creates it (and every lazily built per-batch
+structure: transposed CSR, row orders, in-place column ids).
+"""
+from typing import Callable, Dict, Hashable
+
+import torch
+
+
+class StepGraphs:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
+
+    def warm(self, fn: Callable[[], None], times: int = 2) -> None:
+        """Runs ``fn`` eagerly on the capture stream (lazy initialisation happens here)."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            for _ in range(times):
+                fn()
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def capture(self, key: Hashable, fn: Callable[[], None]) -> None:
+        """Records one execution of ``fn`` (all tensors it reads must stay alive and keep
+        their addresses; whatever it allocates lives in the shared pool)."""
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+            fn()
+        self.graphs[key] = graph
+
+    def replay(self, key: Hashable) -> None:
+        self.graphs[key].replay()
+
+    def __contains__(self, key: Hashable) -> bool:
+        return key in self.graphs

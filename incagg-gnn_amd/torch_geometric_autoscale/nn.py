@@ -248,9 +248,13 @@ def gcn2_batched_terms(convs, x_0: Tensor):
     GEMMs and L accumulations into ``d x_0``) collapse into one wide GEMM each."""
     n_layers, c = len(convs), convs[0].channels
     dev, dt = x_0.device, x_0.dtype
-    beta = torch.tensor([conv.beta for conv in convs], device=dev, dtype=dt).view(-1, 1, 1)
+    consts = convs[0].__dict__.setdefault("_batched_consts", {})
+    if (dev, dt, n_layers) not in consts:   # built once: no host-to-device copy inside a step
+        consts[(dev, dt, n_layers)] = (
+            torch.tensor([conv.beta for conv in convs], device=dev, dtype=dt).view(-1, 1, 1),
+            torch.eye(c, device=dev, dtype=dt))
+    beta, eye = consts[(dev, dt, n_layers)]
     alpha = convs[0].alpha
-    eye = torch.eye(c, device=dev, dtype=dt)
     w1 = torch.stack([conv.weight1 for conv in convs])
     w2 = torch.stack([conv.weight2 for conv in convs])
     w1f = (1.0 - alpha) * (beta * w1 + (1.0 - beta) * eye)

@@ -105,3 +105,76 @@ def test_aggregation_gradients(reduce, dev):
         h.backward(dy)
         want = cp.spmm_t(rowptr, col, val, dy.cpu().numpy(), b, reduce)
         np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_graph_replayed_steps_train_like_eager_steps():
+    """Training steps recorded into HIP graphs (one per batch) and replayed leave the model
+    where the same steps issued eagerly leave it."""
+    import copy
+    import torch_geometric_autoscale as tga
+    from torch_geometric_autoscale.graphs import StepGraphs
+    from torch_geometric_autoscale.loader import partition_batch
+    from torch_geometric_autoscale.models import GCN2
+    dev = torch.device("cuda", 0)
+    adj, ptr = tga.synthetic_graph(6000, 6000 * 14, 6, cross_fraction=0.2, seed=9)
+    adj = tga.gcn_norm(adj.set_diag())
+    g = torch.Generator().manual_seed(2)
+    data = tga.Data(adj_t=adj, num_nodes=6000, x=torch.randn(6000, 20, generator=g),
+                    y=torch.randint(0, 4, (6000,), generator=g))
+    torch.manual_seed(1)
+    base = GCN2(6000, 20, 64, 4, 3, alpha=0.1, theta=0.5, shared_weights=False, dropout=0.0,
+                device=dev).to(dev)
+    for h in base.histories:
+        h.emb.normal_(0, 0.1)
+    batches = []
+    for p in range(4):
+        sub = partition_batch(data, ptr, [p])
+        batches.append((sub.data.x.to(dev), sub.data.adj_t.to(dev), sub.batch_size,
+                        sub.n_id.to(dev), sub.offset, sub.count, sub.data.y[:sub.batch_size].to(dev)))
+
+    tables0 = [h.emb.clone() for h in base.histories]
+
+    def run(graphed):
+        model = copy.deepcopy(base)
+        # plain SGD: rounding-level differences stay rounding-level (Adam would turn them
+        # into +-lr steps wherever a gradient is ~0)
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+
+        def step(k):
+            x, a, b, nid, off, cnt, y = batches[k]
+            out = model(x, a, b, nid, off, cnt)["out"]
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(out, y).backward()
+            opt.step()
+
+        order = [0, 1, 2, 3, 2, 0, 1, 3]
+        if not graphed:
+            for k in order:
+                step(k)
+        else:
+            # warm-up and recording run real steps too: put weights, tables and optimizer
+            # statistics back (in place: the graphs hold their addresses) before replaying
+            state = copy.deepcopy(model.state_dict())
+            graphs = StepGraphs(dev)
+            for k in range(4):
+                graphs.warm(lambda: step(k), times=1)
+            for k in range(4):
+                graphs.capture(k, lambda: step(k))
+            torch.cuda.synchronize()
+            model.load_state_dict(state)
+            for h, t in zip(model.histories, tables0):
+                h.emb.copy_(t)
+            for k in order:
+                graphs.replay(k)
+        torch.cuda.synchronize()
+        return model
+
+    eager, replayed = run(False), run(True)
+    moved = False
+    for (n1, p1), (_, p2), (_, p0) in zip(eager.named_parameters(), replayed.named_parameters(),
+                                          base.named_parameters()):
+        assert torch.allclose(p1, p2, rtol=1e-3, atol=1e-5), n1
+        moved = moved or not torch.equal(p1, p0)
+    assert moved
+    for h1, h2 in zip(eager.histories, replayed.histories):
+        assert torch.allclose(h1.emb, h2.emb, rtol=1e-3, atol=1e-5)
