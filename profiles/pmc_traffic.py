@@ -20,6 +20,8 @@ def per_launch(d, counter, steps, per_step):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     mains = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in MAIN)]
+    # (with HIP graphs bench.py appends an eager pass over the same K steps; both passes run
+    # the same launches, so the tail of the run is representative either way)
     first = mains[-steps * per_step]
     total = sum(float(r["Counter_Value"]) for r in rows[first:]
                 if any(k in r["Kernel_Name"] for k in MAIN + SECOND))
