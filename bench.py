@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the partition-parallel code path even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--unfused-incagg", action="store_true",
+                    help="vr mode: x - M_in as a pass of its own, then the plain aggregation")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay every step from a HIP graph recorded once per batch "
                          "(auto: on for a single GPU)")
@@ -93,6 +95,23 @@ class KernelClock:
             return y
 
         ops.spmm_csr = timed
+        inner_inc = ops.spmm_csr_incagg
+
+        def timed_inc(rowptr32, col32, val, x, m_in, m_ag, *a, **k):
+            if not clock.enabled:
+                return inner_inc(rowptr32, col32, val, x, m_in, m_ag, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = inner_inc(rowptr32, col32, val, x, m_in, m_ag, *a, **k)
+            e.record()
+            n_rows, nnz, f = rowptr32.numel() - 1, col32.numel(), x.size(1)
+            # the plain aggregation's compulsory bytes plus one read each of the M_in and M_ag rows
+            algo = nnz * (4 + (4 if val is not None else 0)) + (n_rows + 1) * 4 + 4 * n_rows * f * 4
+            gather = nnz * (2 * f * 4 + 8) + 2 * n_rows * f * 4
+            clock.records.append((s, e, algo, gather, nnz))
+            return y
+
+        ops.spmm_csr_incagg = timed_inc
 
     def summary(self):
         if not self.records:
@@ -238,6 +257,7 @@ def main():
                  shared_weights=False, dropout=0.0, device=dev).to(dev)
     if sharded:
         model.set_partition_context(ctx)
+    model.fused_incagg = not args.unfused_incagg
     g_cpu = torch.Generator().manual_seed(2)
     with torch.no_grad():
         for p_ in model.parameters():

@@ -151,15 +151,17 @@ def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,
     red = "mean" if reduce == "mean" else "sum"
     if fused:
         return _IncAgg.apply(x, add, m_in, m_ag, adj, red, float(scale), float(add_scale))
-    # two-pass form: one streaming subtract, then the plain aggregation with M_ag
-    # folded in afterwards; gathers touch one operand instead of two.
+    # two-pass form: one streaming subtract, then the plain aggregation with M_ag (and the
+    # caller's add term) riding in its epilogue; gathers touch one operand instead of two.
     d = _RowsSub.apply(x[:b], m_in)
-    h = _SpMM.apply(d, None, None, adj, red, 1.0, 0.0, None) + m_ag[:b, :x.size(1)]
+    w = x.size(1)
+    m_ag = m_ag[:b, :w]
+    if add is None:
+        return _SpMM.apply(d, None, m_ag, adj, red, float(scale), float(scale), None)
+    h = _SpMM.apply(d, None, m_ag, adj, red, 1.0, 1.0, None)
     if scale != 1.0:
         h = h * scale
-    if add is not None:
-        h = h + add_scale * add[:b]
-    return h
+    return h + add_scale * add[:b]
 
 
 class _RowsSub(torch.autograd.Function):

@@ -155,7 +155,7 @@ def check_incagg_forward(name, model, data, ptr, device):
                                 sub.offset, sub.count)
             np.testing.assert_allclose(ret["out"].detach().cpu().numpy(), want, **TOL,
                                        err_msg=f"{name}: VR forward fused={fused} parts {parts}")
-        model.fused_incagg = True
+        model.fused_incagg = False
 
 
 def check_training_step(name, model, data, ptr, device, vr):
