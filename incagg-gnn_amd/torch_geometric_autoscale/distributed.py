@@ -91,10 +91,14 @@ class HaloPlan:
             self._dev[key] = (self.own_local.to(device), self.serve_local.to(device))
         return self._dev[key]
 
-    def exchange(self, shard: Tensor, width: Optional[int] = None,
-                 out: Optional[Tensor] = None) -> Optional[Tensor]:
-        """The batch's out-of-batch rows of one (row-sharded) table, in plan order.
-        Collective: every rank of the group calls it once per (round, layer)."""
+    def start_exchange(self, shard: Tensor, width: Optional[int] = None,
+                       out: Optional[Tensor] = None) -> "PendingHalo":
+        """Starts fetching the batch's out-of-batch rows of one (row-sharded) table: the rows
+        this rank owns and the rows its peers asked for are gathered now, on the current
+        stream; the all-to-all that moves the latter runs asynchronously (on the communication
+        library's own stream) and :meth:`PendingHalo.wait` orders the consumer behind it.
+        Collective: every rank of the group calls it once per (round, layer), in the same
+        order."""
         device = out.device if out is not None else (
             shard.device if shard.is_cuda or not torch.cuda.is_available()
             else torch.device("cuda", torch.cuda.current_device()))
@@ -105,15 +109,35 @@ class HaloPlan:
         n_own = own_local.numel()
         if n_own:
             ops.gather_rows(shard, own_local, out=out[:n_own], device=device)
+        work = send = None
         if self.ctx.world > 1:
             send = ops.gather_rows(shard, serve_local, device=device) if serve_local.numel() \
                 else torch.empty((0, f), dtype=shard.dtype, device=device)
             recv = out[n_own:self.n_halo]
-            dist.all_to_all_single(recv, send, self.recv_counts, self.send_counts,
-                                   group=self.ctx.group)
-        if self.n_halo == 0:
-            return None
-        return out[:self.n_halo] if width is None else out[:self.n_halo, :width]
+            work = dist.all_to_all_single(recv, send, self.recv_counts, self.send_counts,
+                                          group=self.ctx.group, async_op=True)
+        rows = None
+        if self.n_halo:
+            rows = out[:self.n_halo] if width is None else out[:self.n_halo, :width]
+        return PendingHalo(work, rows, send)
+
+    def exchange(self, shard: Tensor, width: Optional[int] = None,
+                 out: Optional[Tensor] = None) -> Optional[Tensor]:
+        """:meth:`start_exchange` and wait: the rows, in plan order."""
+        return self.start_exchange(shard, width, out).wait()
+
+
+class PendingHalo:
+    """Out-of-batch rows on their way (see :meth:`HaloPlan.start_exchange`)."""
+
+    def __init__(self, work, rows: Optional[Tensor], send: Optional[Tensor]):
+        self._work, self._rows, self._send = work, rows, send   # `send` stays alive until waited
+
+    def wait(self) -> Optional[Tensor]:
+        if self._work is not None:
+            self._work.wait()       # RCCL: orders the current stream behind the transfer
+            self._work = self._send = None
+        return self._rows
 
 
 def build_halo_plan(ctx: PartitionContext, halo_ids: Tensor) -> Tuple[HaloPlan, Tensor]:

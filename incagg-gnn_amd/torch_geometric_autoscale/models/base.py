@@ -82,6 +82,7 @@ class ScalableGNN(torch.nn.Module):
         # this rank's rows (construct the model with num_nodes = ctx.local_rows)
         self.partition_ctx = None
         self._current_plan = None
+        self._halo_pending = []   # partition-parallel: exchanges started at the top of a step
         # push/pull forward and refresh sweeps: let the aggregation read out-of-batch rows
         # straight from the HBM-resident table (no gathered copy) whenever nothing has to
         # touch those rows first (no dropout on them, no per-row transform before aggregating)
@@ -203,9 +204,22 @@ class ScalableGNN(torch.nn.Module):
         if self._async and use_aggregation:
             for hist in self.histories[1:]:
                 self.pool.async_pull(hist.emb, None, None, n_id[batch_size:])
+        if (self.partition_ctx is not None and self._current_plan is not None and use_aggregation
+                and batch_size is not None):
+            # Like the pool's pulls above (models/base.py:186-188), the exchanges of ALL layers
+            # start now: out-of-batch rows are historical values either way, and the transfers
+            # over xGMI then overlap with the layers' compute instead of preceding each of them.
+            # (Rows a peer asks for are read before this step's own pushes.)
+            self._halo_pending = [self._current_plan.start_exchange(h.emb)
+                                  for h in self.histories[1:]]
 
-        out, t_move = self.forward(x, adj_t, drift_norm, aggregate_combined, use_aggregation,
-                                   batch_size, n_id, offset, count, **kwargs)
+        try:
+            out, t_move = self.forward(x, adj_t, drift_norm, aggregate_combined, use_aggregation,
+                                       batch_size, n_id, offset, count, **kwargs)
+        finally:
+            for pending in self._halo_pending:     # keep the collectives matched on every path
+                pending.wait()
+            self._halo_pending = []
 
         if self._async:
             self.pool.synchronize_push()
@@ -300,10 +314,12 @@ class ScalableGNN(torch.nn.Module):
             return out, None, None
         x = x if x.size(0) == batch_size else x[:batch_size]
         if self.partition_ctx is not None:
-            # push into the local shard first, then serve / fetch: peers asking for rows of
-            # this very batch get the fresh values
+            # the local push; the out-of-batch rows were requested at the top of the step
+            # (or are fetched now, when nothing was started: direct calls of this method)
             history.push(x.detach(), n_id[:batch_size], self._local(offset), count)
             plan = self._current_plan
+            if self._halo_pending:
+                return x, self._halo_pending.pop(0).wait(), None
             return x, (None if plan is None else plan.exchange(history.emb)), None
         if not self._async:
             history.push(x.detach(), n_id[:batch_size], offset, count)
