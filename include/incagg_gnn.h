@@ -91,6 +91,11 @@ int incagg_check_device_errors(void);
  * max_row_nnz says there is no such row), so such rows are reproducible only up to fp32
  * rounding order.  The slice queue is device memory the library allocates once per
  * (device, stream) on the first call that may need it.
+ * HIP graphs: a call may be recorded into a stream capture once the queue of that stream exists
+ * (run one aggregation on the stream before capturing it; allocation is impossible during
+ * capture and the call fails with a message saying so).  A recorded call keeps using the
+ * queue of the stream it was recorded on, wherever the graph is replayed: replays of such
+ * graphs, and eager aggregations on the recording stream, must not overlap in time.
  */
 int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                         const float *x, int64_t ldx, const float *x_halo, int64_t ld_halo,
