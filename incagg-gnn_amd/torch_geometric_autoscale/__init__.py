@@ -17,7 +17,8 @@ from .history import History  # noqa: E402
 from .pool import AsyncIOPool  # noqa: E402
 from .metis import metis, permute  # noqa: E402
 from .utils import compute_micro_f1, gen_masks, dropout, index2mask  # noqa: E402
-from .loader import SubgraphLoader, EvalSubgraphLoader, SubData  # noqa: E402
+from .loader import (SubgraphLoader, EvalSubgraphLoader, DeviceSubgraphLoader, SubData,  # noqa: E402
+                     partition_batch, device_partition_batch)
 from .aggregate import spmm, incagg_aggregate  # noqa: E402
 from . import models  # noqa: E402
 from . import distributed  # noqa: E402

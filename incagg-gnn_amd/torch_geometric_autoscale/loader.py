@@ -116,6 +116,39 @@ def device_partition_batch(data: Data, ptr: Tensor, part_ids, device,
     return SubData(out, batch_size, n_id, offset, count)
 
 
+class DeviceSubgraphLoader:
+    """Partition batches built on the GPU (:func:`device_partition_batch`): the counterpart of
+    :class:`SubgraphLoader` / :class:`EvalSubgraphLoader` for a graph that is resident in HBM.
+    Iterating yields ``SubData`` tuples for consecutive groups of ``batch_size`` partitions, in
+    a fresh random order per pass when ``shuffle``.  Batches of fixed groups (no shuffling, or
+    one partition per batch) are built once and kept -- with their transposed CSR, row orders
+    and in-place column ids, which hang off the adjacency object."""
+
+    def __init__(self, data: Data, ptr: Tensor, device, batch_size: int = 1, shuffle: bool = False,
+                 in_batch_only: bool = False):
+        self.data, self.ptr, self.device = data, ptr, torch.device(device)
+        self.batch_size, self.shuffle, self.in_batch_only = batch_size, shuffle, in_batch_only
+        self.num_parts = ptr.numel() - 1
+        self._cache = {} if (not shuffle or batch_size == 1) else None
+
+    def __len__(self) -> int:
+        return -(-self.num_parts // self.batch_size)
+
+    def _build(self, parts) -> SubData:
+        if self._cache is None:
+            return device_partition_batch(self.data, self.ptr, parts, self.device, self.in_batch_only)
+        key = tuple(parts)
+        if key not in self._cache:
+            self._cache[key] = device_partition_batch(self.data, self.ptr, parts, self.device,
+                                                      self.in_batch_only)
+        return self._cache[key]
+
+    def __iter__(self):
+        order = torch.randperm(self.num_parts).tolist() if self.shuffle else list(range(self.num_parts))
+        for i in range(0, self.num_parts, self.batch_size):
+            yield self._build(order[i:i + self.batch_size])
+
+
 class SubgraphLoader(DataLoader):
     r"""A simple subgraph loader that, given a pre-partioned :obj:`data` object,
     generates subgraphs from mini-batches in :obj:`ptr` (including their 1-hop

@@ -26,7 +26,7 @@ import torch
 
 from . import models
 from .data import gcn_norm, get_data
-from .loader import EvalSubgraphLoader, SubgraphLoader
+from .loader import DeviceSubgraphLoader, EvalSubgraphLoader, SubgraphLoader
 from .metis import load_partition, metis, permute
 from .utils import compute_micro_f1, dropout
 
@@ -37,6 +37,9 @@ DEFAULTS: Dict[str, Any] = {
     "dropout": None, "num_neighbors": -1, "drift_norm": 2, "period_updates_in_one_epoch": 0,
     "aggregate_combined": True, "use_aggregation": True, "partition_file": None,
     "history_device": "model", "synthetic_scale": 1.0,
+    # "device": graph, features and labels live in HBM and batches are built there by the HIP
+    # batch builder (needs a GPU); "host": the reference's DataLoader path (loader.py:95-284)
+    "batch_builder": "auto",
     "dataset": {"name": "arxiv"},
     "model": {"name": "GCN", "norm": True, "loop": True, "params": {}},
 }
@@ -189,10 +192,23 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
 
     vr = bool(conf["VR_update"])
     loader_data = data.__class__(**{k: v for k, v in data if k != "ptr"})
-    train_loader = SubgraphLoader(loader_data, ptr, batch_size=batch_size, shuffle=True,
-                                  num_workers=int(params.get("num_workers", 0)),
-                                  num_neighbors=conf["num_neighbors"], type='train', IB=vr, log=False)
-    eval_loader = EvalSubgraphLoader(loader_data, ptr, batch_size=batch_size, log=False)
+    builder = conf["batch_builder"]
+    if builder == "auto":   # neighbour sampling is host-side only
+        builder = "device" if (device.type == "cuda" and conf["num_neighbors"] in (-1, None)
+                               and conf["history_device"] == "model") else "host"
+    if builder == "device":
+        dev_data = loader_data.__class__(**{
+            k: (v.to(device) if isinstance(v, torch.Tensor) and k != "adj_t" else v)
+            for k, v in loader_data})
+        train_loader = DeviceSubgraphLoader(dev_data, ptr, device, batch_size=batch_size,
+                                            shuffle=True, in_batch_only=vr)
+        eval_loader = DeviceSubgraphLoader(dev_data, ptr, device, batch_size=batch_size)
+    else:
+        train_loader = SubgraphLoader(loader_data, ptr, batch_size=batch_size, shuffle=True,
+                                      num_workers=int(params.get("num_workers", 0)),
+                                      num_neighbors=conf["num_neighbors"], type='train', IB=vr,
+                                      log=False)
+        eval_loader = EvalSubgraphLoader(loader_data, ptr, batch_size=batch_size, log=False)
     buffer_size = max(n_id.numel() for _, _, n_id, _, _ in eval_loader) * 2     # main.py:177
 
     GNN = getattr(models, conf["model"]["name"])

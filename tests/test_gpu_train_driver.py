@@ -47,3 +47,15 @@ def test_driver_with_host_tables_and_staging_pools():
                           history_device="host"))
     _lib.check_device_errors()
     assert res["history"][-1]["loss"] < res["history"][0]["loss"]
+
+
+def test_driver_with_host_and_device_batch_builders():
+    """Both batch builders drive the same training loop (batch order differs: the loaders
+    shuffle with different generators), and both runs learn."""
+    from torch_geometric_autoscale import train
+    for builder in ("host", "device"):
+        conf = _conf("GCN2", False, {"alpha": 0.1, "theta": 0.5, "shared_weights": False,
+                                     "dropout": 0.0}, batch_builder=builder)
+        res = train.run(conf)
+        assert res["history"][-1]["loss"] < res["history"][0]["loss"], builder
+        assert res["val"] > 0.3, (builder, res["val"])
