@@ -306,6 +306,11 @@ def main():
         torch.cuda.synchronize()
         for k in range(len(batches)):
             graphs.capture(k, lambda: eager_step(k))
+            if os.environ.get("BENCH_TRACE") and k % 10 == 9:
+                torch.cuda.synchronize()
+                print(f"captured {k + 1} step graphs, "
+                      f"{torch.cuda.memory_allocated() / 2**30:.1f} GiB allocated", file=sys.stderr,
+                      flush=True)
         torch.cuda.synchronize()
 
     # Untimed priming before the W warmup steps: every prepared batch once (batches differ in

@@ -52,16 +52,23 @@ def mini_train(model, loader, criterion, optimizer, max_steps, grad_norm=None, e
     """One training epoch (main.py:47-96).  Batches without training nodes are skipped; the
     loss is averaged over training nodes; the epoch stops after ``max_steps`` batches."""
     model.train()
-    total_loss, total_examples = 0.0, 0
+    total_loss, total_examples = 0.0, 0     # the loss sum stays on the device until the end
     for i, (batch, batch_size, n_id, offset, count) in enumerate(loader):
         x = batch.x.to(model.device)
         adj_t = batch.adj_t.to(model.device)
         y = batch.y[:batch_size].to(model.device)
         train_mask = batch.train_mask[:batch_size].to(model.device)
-        n_train = int(train_mask.sum())
+        n_train = batch.__dict__.get("_n_train")       # counted once per batch object
+        if n_train is None:
+            n_train = int(train_mask.sum())
+            batch.__dict__["_n_train"] = n_train
+            # row numbers instead of a boolean mask: indexing with them has a static shape
+            batch.__dict__["_train_idx"] = train_mask.nonzero(as_tuple=False).view(-1)
         if n_train == 0:
             continue
+        train_idx = batch.__dict__["_train_idx"]
         adj_t = dropout(adj_t, p=edge_dropout)
+
         if VR_update:
             ret = model.VR_call(x, adj_t, batch_size, n_id, offset, count, debug_flag=debug_flag,
                                 drift_norm=drift_norm, epoch=epoch, batch_idx=i)
@@ -70,17 +77,18 @@ def mini_train(model, loader, criterion, optimizer, max_steps, grad_norm=None, e
                         aggregate_combined=aggregate_combined, use_aggregation=use_aggregation)
         out = ret['out']
         optimizer.zero_grad()
-        loss = criterion(out[train_mask], y[train_mask])
+        loss = criterion(out.index_select(0, train_idx), y.index_select(0, train_idx))
         loss.backward()
         if grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
         optimizer.step()
-        total_loss += float(loss.detach()) * n_train
+        loss = loss.detach()
+        total_loss = total_loss + loss * n_train
         total_examples += n_train
         # the epoch may stop early so that the tables get refreshed (main.py:90-92)
         if (i + 1) >= max_steps and (i + 1) < len(loader):
             break
-    return {"loss": total_loss / max(total_examples, 1)}
+    return {"loss": float(total_loss) / max(total_examples, 1)}
 
 
 @torch.no_grad()
@@ -172,9 +180,13 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
     num_parts = int(params["num_parts"])
 
     t = time.perf_counter()
+    # synthetic graphs are sampled, given self loops and normalised on the GPU when there is one
+    # (seconds instead of minutes at ogbn-products size), then handed to the host-side loaders
+    on_gpu = device.type == "cuda"
     data, in_channels, out_channels = get_data(conf["root"], name, num_parts=num_parts,
                                                scale=float(conf["synthetic_scale"]), seed=seed,
-                                               planted_labels=True)
+                                               planted_labels=True, device=device,
+                                               keep_on_device=on_gpu)
     log.info(f"data ready [{time.perf_counter() - t:.2f}s]")
     if conf.get("partition_file"):
         perm, ptr = load_partition(conf["partition_file"], data.num_nodes)
@@ -188,6 +200,8 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
         data.adj_t = data.adj_t.set_diag()
     if conf["model"].get("norm", True):
         data.adj_t = gcn_norm(data.adj_t, add_self_loops=False)
+    if data.adj_t.device().type != "cpu":
+        data.adj_t = data.adj_t.to("cpu")
     criterion = torch.nn.CrossEntropyLoss() if data.y.dim() == 1 else torch.nn.BCEWithLogitsLoss()
 
     vr = bool(conf["VR_update"])
