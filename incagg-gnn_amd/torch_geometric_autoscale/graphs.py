@@ -11,6 +11,14 @@ replayed one after the other, never concurrently).  The aggregation library need
 per-stream slice queue to exist before a stream is captured; :meth:`StepGraphs.warm` runs the
 step eagerly on the capture stream first, which creates it (and every lazily built per-batch
 structure: transposed CSR, row orders, in-place column ids).
+
+Known limitation (observed on ROCm 7.0 / torch 2.10, cause not established): replaying recorded
+steps AFTER other work had been issued eagerly on the device since the recording -- a refresh
+sweep between two epochs of replays -- ended in an illegal memory access, while the same
+graphs replay indefinitely when nothing eager runs in between (warm everything, record
+everything, then only replay: what ``bench.py`` does), and recording / replaying interleaved
+with eager *training steps* is fine too.  Until that is understood, loops that alternate
+training epochs with eager sweeps (``train.run``) issue their steps eagerly.
 """
 from typing import Callable, Dict, Hashable
 
