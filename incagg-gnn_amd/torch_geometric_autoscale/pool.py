@@ -99,12 +99,13 @@ class AsyncIOPool(torch.nn.Module):
                 numel = 0 if count is None else int(count.sum())
                 if numel + index.numel() > self.buffer_size:
                     raise RuntimeError("Buffer tensor size too small")
-                ops.read_async(src, offset, count, index[:0], dst, self._cpu_buffer(idx))
+                no_index = torch.empty(0, dtype=torch.int64)     # (the staging op wants host ids)
+                ops.read_async(src, offset, count, no_index, dst, self._cpu_buffer(idx))
                 idx_dev = index.to(self._device, non_blocking=True)
                 ops.gather_rows(src, idx_dev, out=dst[numel:numel + index.numel()],
                                 device=self._device)
             else:
-                ops.read_async(src, offset, count, index, dst, self._cpu_buffer(idx))
+                ops.read_async(src, offset, count, index.cpu(), dst, self._cpu_buffer(idx))
 
     @torch.no_grad()
     def synchronize_pull(self) -> Tensor:

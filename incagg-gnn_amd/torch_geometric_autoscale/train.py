@@ -208,8 +208,8 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
     loader_data = data.__class__(**{k: v for k, v in data if k != "ptr"})
     builder = conf["batch_builder"]
     if builder == "auto":   # neighbour sampling is host-side only
-        builder = "device" if (device.type == "cuda" and conf["num_neighbors"] in (-1, None)
-                               and conf["history_device"] == "model") else "host"
+        builder = "device" if device.type == "cuda" and conf["num_neighbors"] in (-1, None) \
+            else "host"
     if builder == "device":
         dev_data = loader_data.__class__(**{
             k: (v.to(device) if isinstance(v, torch.Tensor) and k != "adj_t" else v)
