@@ -662,12 +662,15 @@ __global__ __launch_bounds__(256) void rows_sub_kernel(const float *a, long long
 // ---------------------------------------------------------------- host side
 struct HubQueue {
   int2 *entries = nullptr;
-  // words 0 / 1 are used alternately by eager calls (the idle one is zero: each slice kernel
-  // clears the word of the next call); word 2 belongs to calls recorded into a HIP graph,
-  // which clear it with a recorded memset instead -- a replayed call runs none of this host
-  // code, so it cannot take part in the alternation; word 3 is a scratch target.
+  // Two pairs of counter words, each used alternately (the idle word of a pair is zero: every
+  // slice kernel clears the word of the next call).  Words 0 / 1 serve eager calls.  Words 2 / 3
+  // serve calls that are being recorded into a HIP graph: a replay runs none of this host code,
+  // so the alternation cannot carry over from one recording to the next -- the first call of
+  // every recording therefore clears both words with one recorded memset and starts at word 2.
   int *counters = nullptr;
   int parity = 0;
+  int capture_parity = 0;
+  unsigned long long capture_id = ~0ull;
 };
 
 static std::mutex s_queue_mutex;
@@ -703,21 +706,27 @@ static int hub_queue_for(hipStream_t stream, HubQueue **out) {
 }
 
 // Points the launch at the queue's counters.  `advance` is set when the caller has to flip the
-// parity after its two launches (eager call); a call that is being captured gets its own word,
-// cleared by a memset that is recorded in front of it.
+// parity after its two launches (eager call); calls that are being captured alternate a pair
+// of words of their own, which one recorded memset clears at the start of every recording.
 static int bind_queue(SpmmArgs &a, HubQueue *q, hipStream_t stream, bool *advance) {
   a.queue = q->entries;
   a.q_cap = kQueueCap;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  INCAGG_HIP_TRY(hipStreamIsCapturing(stream, &cap));
+  unsigned long long id = 0;
+  INCAGG_HIP_TRY(hipStreamGetCaptureInfo(stream, &cap, &id));
   if (cap == hipStreamCaptureStatusNone) {
     a.q_count = q->counters + q->parity;
     a.q_count_next = q->counters + (q->parity ^ 1);
     *advance = true;
   } else {
-    INCAGG_HIP_TRY(hipMemsetAsync(q->counters + 2, 0, sizeof(int), stream));
-    a.q_count = q->counters + 2;
-    a.q_count_next = q->counters + 3;
+    if (id != q->capture_id) {  // first aggregation of this recording
+      INCAGG_HIP_TRY(hipMemsetAsync(q->counters + 2, 0, 2 * sizeof(int), stream));
+      q->capture_id = id;
+      q->capture_parity = 0;
+    }
+    a.q_count = q->counters + 2 + q->capture_parity;
+    a.q_count_next = q->counters + 2 + (q->capture_parity ^ 1);
+    q->capture_parity ^= 1;
     *advance = false;
   }
   return INCAGG_OK;
