@@ -576,10 +576,14 @@ class ScalableGNN(torch.nn.Module):
                     # in-batch rows by chunks (the update needs them); out-of-batch rows are
                     # read from the table by the aggregation itself
                     hist = self.histories[i]
-                    x = torch.empty((batch_size, hist.embedding_dim), dtype=hist.emb.dtype,
-                                    device=self.device)
-                    ops.copy_row_chunks(x, hist.emb, offset, count, packed_is_src=False,
+                    if count.numel() == 1:      # one contiguous range: the table rows themselves
+                        o = int(offset[0])
+                        x = hist.emb[o:o + batch_size]
+                    else:
+                        x = torch.empty((batch_size, hist.embedding_dim), dtype=hist.emb.dtype,
                                         device=self.device)
+                        ops.copy_row_chunks(x, hist.emb, offset, count, packed_is_src=False,
+                                            device=self.device)
                     halo = hist.emb
                     halo_ids = ids_on_device(data, n_id)[batch_size:]
                 else:

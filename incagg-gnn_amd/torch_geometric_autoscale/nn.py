@@ -207,11 +207,22 @@ class GCN2Conv(torch.nn.Module):
     def _folded(self, weight: Tensor, scale: float) -> Tensor:
         """``scale * (beta * W + (1 - beta) * I)``: the identity part of
         ``(1 - beta) p + beta p W`` folded into the weight, so that the layer is one GEMM
-        per term and no elementwise pass over the [rows, channels] activations."""
+        per term and no elementwise pass over the [rows, channels] activations.  Without
+        autograd (the refresh sweeps visit every batch with the same weights) the result is
+        kept until the weight changes."""
         eye = self._eye
         if eye is None or eye.device != weight.device:
             eye = self._eye = torch.eye(self.channels, device=weight.device, dtype=weight.dtype)
-        return torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta)
+        if torch.is_grad_enabled():
+            return torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta)
+        cache = self.__dict__.setdefault("_folded_cache", {})
+        key = (id(weight), scale)
+        hit = cache.get(key)
+        if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+            hit = (weight._version,
+                   torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta))
+            cache[key] = hit
+        return hit[1]
 
     def forward_after_propagate(self, h: Tensor, x_0: Tensor, w1_folded: Optional[Tensor] = None,
                                 x0_term: Optional[Tensor] = None) -> Tensor:
