@@ -240,8 +240,18 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_hub_kernel(const S
     const int row = rfl(ent.x);
     if (row < 0) continue;
     const int k = rfl(ent.y);
+    // an entry is followed only if it names a row and a slice of THIS call's matrix: the
+    // queue outlives the call, and an entry that is not ours must be reported, not read
+    if (row >= a.n_rows || k < 0) {
+      *a.err = 1;
+      continue;
+    }
     const int rs0 = rfl(a.rowptr[row]);
     const int re0 = rfl(a.rowptr[row + 1]);
+    if ((long long)k * a.hub_slice >= (long long)(re0 - rs0)) {
+      *a.err = 1;
+      continue;
+    }
     const int rs = rs0 + k * a.hub_slice;
     const int re = min(re0, rs + a.hub_slice);
     V acc[CH];
@@ -507,8 +517,18 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_sliced_hub_kernel(
     const int row = rfl(ent.x);
     if (row < 0) continue;
     const int k = rfl(ent.y);
+    // an entry is followed only if it names a row and a slice of THIS call's matrix: the
+    // queue outlives the call, and an entry that is not ours must be reported, not read
+    if (row >= a.n_rows || k < 0) {
+      *a.err = 1;
+      continue;
+    }
     const int rs0 = rfl(a.rowptr[row]);
     const int re0 = rfl(a.rowptr[row + 1]);
+    if ((long long)k * a.hub_slice >= (long long)(re0 - rs0)) {
+      *a.err = 1;
+      continue;
+    }
     const int rs = rs0 + k * a.hub_slice;
     const int re = min(re0, rs + a.hub_slice);
     f4 acc = f4(0.f);

@@ -18,7 +18,10 @@ sweep between two epochs of replays -- ended in an illegal memory access, while 
 graphs replay indefinitely when nothing eager runs in between (warm everything, record
 everything, then only replay: what ``bench.py`` does), and recording / replaying interleaved
 with eager *training steps* is fine too.  Until that is understood, loops that alternate
-training epochs with eager sweeps (``train.run``) issue their steps eagerly.
+training epochs with eager sweeps (``train.run``) issue their steps eagerly.  (The slice
+kernels of the aggregation check every queue entry against the row count and row length of the
+call they belong to and report a foreign entry through the device error flag instead of
+following it, so a stale queue cannot be what turns into a memory fault.)
 """
 from typing import Callable, Dict, Hashable
 
