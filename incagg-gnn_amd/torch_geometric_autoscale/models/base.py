@@ -513,6 +513,16 @@ class ScalableGNN(torch.nn.Module):
 
     @torch.no_grad()
     def _sweep(self, loader, use_aggregation: bool, with_aggregates: bool) -> Tensor:
+        holders = [m for m in self.modules() if hasattr(m, "hold_folded_weights")]
+        for m in holders:       # weights are constant for the duration of a sweep
+            m.hold_folded_weights(True)
+        try:
+            return self._sweep_layers(loader, use_aggregation, with_aggregates)
+        finally:
+            for m in holders:
+                m.hold_folded_weights(False)
+
+    def _sweep_layers(self, loader, use_aggregation: bool, with_aggregates: bool) -> Tensor:
         batches = [tuple(sub) + ({}, ) for sub in loader]
         use_pool = self.pool is not None
         pool = self.pool if use_pool else None

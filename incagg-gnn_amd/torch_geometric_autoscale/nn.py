@@ -204,25 +204,32 @@ class GCN2Conv(torch.nn.Module):
         """``A x`` (kept un-mixed so that :meth:`forward_after_propagate` takes it)."""
         return spmm(adj_t, x)
 
+    def hold_folded_weights(self, hold: bool) -> None:
+        """Between ``hold_folded_weights(True)`` and ``(False)`` the caller promises that the
+        weights do not change (a refresh sweep visits every batch with the same weights):
+        folded weights are then computed once and reused.  Both calls drop what was kept, so
+        nothing survives from one such span to the next -- weights may have been updated in
+        between by code this module never sees (a replayed HIP graph, an optimizer)."""
+        self._hold_folds = bool(hold)
+        self._held_folds = {}
+
     def _folded(self, weight: Tensor, scale: float) -> Tensor:
         """``scale * (beta * W + (1 - beta) * I)``: the identity part of
         ``(1 - beta) p + beta p W`` folded into the weight, so that the layer is one GEMM
-        per term and no elementwise pass over the [rows, channels] activations.  Without
-        autograd (the refresh sweeps visit every batch with the same weights) the result is
-        kept until the weight changes."""
+        per term and no elementwise pass over the [rows, channels] activations."""
         eye = self._eye
         if eye is None or eye.device != weight.device:
             eye = self._eye = torch.eye(self.channels, device=weight.device, dtype=weight.dtype)
-        if torch.is_grad_enabled():
-            return torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta)
-        cache = self.__dict__.setdefault("_folded_cache", {})
-        key = (id(weight), scale)
-        hit = cache.get(key)
-        if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
-            hit = (weight._version,
-                   torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta))
-            cache[key] = hit
-        return hit[1]
+        held = getattr(self, "_hold_folds", False) and not torch.is_grad_enabled()
+        if held:
+            key = "w2" if weight is self.weight2 else "w1"
+            hit = self._held_folds.get((key, scale))
+            if hit is not None and hit.device == weight.device:
+                return hit
+        out = torch.add(eye * (scale * (1.0 - self.beta)), weight, alpha=scale * self.beta)
+        if held:
+            self._held_folds[(key, scale)] = out
+        return out
 
     def forward_after_propagate(self, h: Tensor, x_0: Tensor, w1_folded: Optional[Tensor] = None,
                                 x0_term: Optional[Tensor] = None) -> Tensor:

@@ -1,22 +1,22 @@
-"""Ring of staging slots between pinned-host History tables and HBM (interface and queue
-discipline of the reference's ``AsyncIOPool``, pool.py:15-123).
+"""Ring of staging slots between pinned-host History tables and HBM: the public surface and
+the queue discipline of the reference's ``AsyncIOPool`` (pool.py:15-123).
 
-Each of the ``pool_size`` slots owns a pull stream, a push stream, a pinned host
-buffer and a device buffer of ``[buffer_size, embedding_dim]``.  Pull requests enter
-a FIFO; at most ``pool_size`` are in flight, the rest start as slots are freed.
+A slot (:class:`_Slot`) owns a pull stream, a push stream, a pinned host bounce buffer and a
+device buffer of ``[buffer_size, embedding_dim]``, all created on first use.  Pull requests
+(:class:`_Pull`) are handed slots round-robin and wait in a FIFO; the first ``pool_size`` of
+them are in flight, every ``free_pull`` starts the oldest one that is not.
 
-Differences in mechanism (not in results):
+How it moves the data differs from the reference (the rows delivered do not):
 
-* no host-blocking stream synchronisation -- consumers are ordered behind the copies
-  with stream waits, and a slot's device buffer is only refilled after the compute
-  stream has passed the point where it was freed;
-* with ``zero_copy=True`` (default) the gathered part of a pull is a HIP kernel on
-  the pull stream that reads the pinned table directly over the host link, instead
-  of a single-threaded host gather into the pinned bounce buffer followed by a copy
-  (csrc/cuda/async_cuda.cu:95-110).  Contiguous chunks always go through the DMA
-  engines (hipMemcpyAsync).
+* nothing blocks the host on a stream -- consumers are ordered behind the copies with
+  stream waits, and a slot's device buffer is refilled only behind the kernels that were
+  queued on the compute stream while it was handed out;
+* with ``zero_copy=True`` (default) the gathered part of a pull is a HIP kernel on the pull
+  stream that reads the pinned table over the host link, instead of a single-threaded host
+  gather into the bounce buffer followed by a copy (csrc/cuda/async_cuda.cu:95-110);
+  contiguous chunks always go through the DMA engines (hipMemcpyAsync).
 """
-from typing import Callable, Optional
+from typing import Callable, List, NamedTuple, Optional
 
 import torch
 from torch import Tensor
@@ -24,143 +24,154 @@ from torch import Tensor
 from . import ops
 
 
+class _Pull(NamedTuple):
+    slot: int
+    src: Tensor
+    offset: Optional[Tensor]
+    count: Optional[Tensor]
+    index: Tensor
+
+
+class _Slot:
+    """Resources of one ring entry; every member appears when it is first asked for."""
+
+    def __init__(self, owner: "AsyncIOPool"):
+        self._owner = owner
+        self._streams = {}
+        self._host: Optional[Tensor] = None
+        self._dev: Optional[Tensor] = None
+        self.pushed: Optional[Tensor] = None      # source of the push in flight, kept alive
+
+    def stream(self, kind: str):
+        if kind not in self._streams:
+            dev = self._owner._device
+            if dev.type != "cuda":
+                raise RuntimeError("the staging pool moves rows to a GPU: call .to(device) first")
+            self._streams[kind] = torch.cuda.Stream(dev)
+        return self._streams[kind]
+
+    def has_stream(self, kind: str) -> bool:
+        return kind in self._streams
+
+    def host_buffer(self) -> Tensor:
+        if self._host is None:
+            o = self._owner
+            self._host = torch.empty(o.buffer_size, o.embedding_dim, pin_memory=True)
+        return self._host
+
+    def device_buffer(self) -> Tensor:
+        if self._dev is None:
+            o = self._owner
+            if o._device.type != "cuda":
+                raise RuntimeError("the staging pool moves rows to a GPU: call .to(device) first")
+            self._dev = torch.empty(o.buffer_size, o.embedding_dim, device=o._device)
+        return self._dev
+
+
 class AsyncIOPool(torch.nn.Module):
     def __init__(self, pool_size: int, buffer_size: int, embedding_dim: int,
                  zero_copy: bool = True):
         super().__init__()
-
         self.pool_size = pool_size
         self.buffer_size = buffer_size
         self.embedding_dim = embedding_dim
         self.zero_copy = zero_copy
-
         self._device = torch.device('cpu')
-        self._pull_queue = []
-        self._push_cache = [None] * pool_size
-        self._push_streams = [None] * pool_size
-        self._pull_streams = [None] * pool_size
-        self._cpu_buffers = [None] * pool_size
-        self._cuda_buffers = [None] * pool_size
-        self._pull_index = -1
-        self._push_index = -1
+        self._slots = [_Slot(self) for _ in range(pool_size)]
+        self.pending: List[_Pull] = []      # FIFO of pulls issued and not yet freed
+        self.last_pull_slot = -1            # round-robin cursors; -1 = ring idle
+        self.last_push_slot = -1
 
     def _apply(self, fn: Callable, *args, **kwargs) -> None:
         self._device = fn(torch.zeros(1)).device
         return self
 
-    # ---- lazily created per-slot resources (pool.py:37-62)
-    def _pull_stream(self, idx: int):
-        if self._pull_streams[idx] is None:
-            assert str(self._device)[:4] == 'cuda'
-            self._pull_streams[idx] = torch.cuda.Stream(self._device)
-        return self._pull_streams[idx]
-
-    def _push_stream(self, idx: int):
-        if self._push_streams[idx] is None:
-            assert str(self._device)[:4] == 'cuda'
-            self._push_streams[idx] = torch.cuda.Stream(self._device)
-        return self._push_streams[idx]
-
-    def _cpu_buffer(self, idx: int) -> Tensor:
-        if self._cpu_buffers[idx] is None:
-            self._cpu_buffers[idx] = torch.empty(self.buffer_size, self.embedding_dim,
-                                                 pin_memory=True)
-        return self._cpu_buffers[idx]
-
-    def _cuda_buffer(self, idx: int) -> Tensor:
-        if self._cuda_buffers[idx] is None:
-            assert str(self._device)[:4] == 'cuda'
-            self._cuda_buffers[idx] = torch.empty(self.buffer_size, self.embedding_dim,
-                                                  device=self._device)
-        return self._cuda_buffers[idx]
-
-    # ---- pull side
+    # ------------------------------------------------------------------ pulls
     @torch.no_grad()
     def async_pull(self, src: Tensor, offset: Optional[Tensor], count: Optional[Tensor],
                    index: Tensor) -> None:
-        # Start pulling `src` at ([offset, count] and index positions:
-        self._pull_index = (self._pull_index + 1) % self.pool_size
-        data = (self._pull_index, src, offset, count, index)
-        self._pull_queue.append(data)
-        if len(self._pull_queue) <= self.pool_size:
-            self._async_pull(self._pull_index, src, offset, count, index)
+        """Queues the pull of ``src[offset_i : offset_i + count_i]`` followed by
+        ``src[index]`` (pool.py:64-74); it starts right away while a slot is free."""
+        self.last_pull_slot = (self.last_pull_slot + 1) % self.pool_size
+        req = _Pull(self.last_pull_slot, src, offset, count, index)
+        self.pending.append(req)
+        if len(self.pending) <= self.pool_size:
+            self._start_pull(req)
 
     @torch.no_grad()
-    def _async_pull(self, idx: int, src: Tensor, offset: Optional[Tensor],
-                    count: Optional[Tensor], index: Tensor) -> None:
-        stream = self._pull_stream(idx)
-        dst = self._cuda_buffer(idx)
-        # The slot's device buffer may still be read by kernels already queued on the
-        # compute stream: refill it only behind them.
+    def _start_pull(self, req: _Pull) -> None:
+        slot = self._slots[req.slot]
+        stream, dst = slot.stream("pull"), slot.device_buffer()
+        src, offset, count, index = req.src, req.offset, req.count, req.index
+        # kernels already queued on the compute stream may still read this buffer
         stream.wait_stream(torch.cuda.current_stream(self._device))
         with torch.cuda.stream(stream):
-            if self.zero_copy and index.numel() > 0 and src.is_pinned() \
-                    and src.dtype == torch.float32:
-                numel = 0 if count is None else int(count.sum())
-                if numel + index.numel() > self.buffer_size:
-                    raise RuntimeError("Buffer tensor size too small")
-                no_index = torch.empty(0, dtype=torch.int64)     # (the staging op wants host ids)
-                ops.read_async(src, offset, count, no_index, dst, self._cpu_buffer(idx))
-                idx_dev = index.to(self._device, non_blocking=True)
-                ops.gather_rows(src, idx_dev, out=dst[numel:numel + index.numel()],
-                                device=self._device)
-            else:
-                ops.read_async(src, offset, count, index.cpu(), dst, self._cpu_buffer(idx))
+            kernel_gather = (self.zero_copy and index.numel() > 0 and src.is_pinned()
+                             and src.dtype == torch.float32)
+            if not kernel_gather:
+                ops.read_async(src, offset, count, index.cpu(), dst, slot.host_buffer())
+                return
+            n_chunk_rows = 0 if count is None else int(count.sum())
+            if n_chunk_rows + index.numel() > self.buffer_size:
+                raise RuntimeError("Buffer tensor size too small")
+            ops.read_async(src, offset, count, torch.empty(0, dtype=torch.int64), dst,
+                           slot.host_buffer())
+            ids = index.to(self._device, non_blocking=True)
+            ops.gather_rows(src, ids, out=dst[n_chunk_rows:n_chunk_rows + index.numel()],
+                            device=self._device)
 
     @torch.no_grad()
     def synchronize_pull(self) -> Tensor:
-        idx = self._pull_queue[0][0]
-        ops.synchronize()  # every copy of the oldest pull has been enqueued on its stream
-        torch.cuda.current_stream(self._device).wait_stream(self._pull_stream(idx))
-        return self._cuda_buffer(idx)
+        """The device buffer of the OLDEST pending pull, usable on the current stream
+        (pool.py:83-88).  It stays valid until :meth:`free_pull`."""
+        slot = self._slots[self.pending[0].slot]
+        ops.synchronize()       # the worker has enqueued every copy of that pull
+        torch.cuda.current_stream(self._device).wait_stream(slot.stream("pull"))
+        return slot.device_buffer()
 
     @torch.no_grad()
     def free_pull(self) -> None:
-        # Free the buffer space and start pulling from remaining queue:
-        self._pull_queue.pop(0)
-        if len(self._pull_queue) >= self.pool_size:
-            data = self._pull_queue[self.pool_size - 1]
-            idx, src, offset, count, index = data
-            self._async_pull(idx, src, offset, count, index)
-        elif len(self._pull_queue) == 0:
-            self._pull_index = -1
+        """Retires the oldest pull and starts the oldest one still waiting for a slot
+        (pool.py:90-99)."""
+        del self.pending[0]
+        if len(self.pending) >= self.pool_size:
+            self._start_pull(self.pending[self.pool_size - 1])
+        elif not self.pending:
+            self.last_pull_slot = -1
 
-    # ---- push side
+    # ------------------------------------------------------------------ pushes
     @torch.no_grad()
     def async_push(self, src: Tensor, offset: Tensor, count: Tensor, dst: Tensor) -> None:
-        # Start pushing `src` to ([offset, count] and index positions to `dst`:
-        self._push_index = (self._push_index + 1) % self.pool_size
-        self.synchronize_push(self._push_index)
-        if not src.is_contiguous():
-            src = src.contiguous()
-        self._push_cache[self._push_index] = src
-        stream = self._push_stream(self._push_index)
-        # `src` is produced on the compute stream: copy it out only once it is complete.
-        stream.wait_stream(torch.cuda.current_stream(self._device))
+        """Copies the rows of ``src`` to ``dst[offset_i : offset_i + count_i]`` on the next
+        slot's push stream (pool.py:101-109)."""
+        self.last_push_slot = (self.last_push_slot + 1) % self.pool_size
+        self.synchronize_push(self.last_push_slot)
+        slot = self._slots[self.last_push_slot]
+        src = src if src.is_contiguous() else src.contiguous()
+        slot.pushed = src
+        stream = slot.stream("push")
+        stream.wait_stream(torch.cuda.current_stream(self._device))   # src is complete first
         with torch.cuda.stream(stream):
             ops.write_async(src, offset, count, dst)
         src.record_stream(stream)
 
     @torch.no_grad()
     def synchronize_push(self, idx: Optional[int] = None) -> None:
-        # Synchronize the push command of stream `idx` or all commands:
+        """Waits for the push of slot ``idx``, or for all of them (pool.py:111-123).  A real
+        completion wait: the host reads the pinned table afterwards."""
         if idx is None:
-            for idx in range(self.pool_size):
-                self.synchronize_push(idx)
-            self._push_index = -1
-        else:
-            # The pinned table is read by the HOST afterwards (the next pull gathers
-            # from it), so this one has to be a real completion wait.
-            if self._push_streams[idx] is not None:
-                self._push_streams[idx].synchronize()
-            self._push_cache[idx] = None
+            for i in range(self.pool_size):
+                self.synchronize_push(i)
+            self.last_push_slot = -1
+            return
+        slot = self._slots[idx]
+        if slot.has_stream("push"):
+            slot.stream("push").synchronize()
+        slot.pushed = None
 
     def forward(self, *args, **kwargs):
-        """"""
-        raise NotImplementedError
+        raise NotImplementedError("AsyncIOPool is driven through async_pull / async_push")
 
-    def __repr__(self):
-        return (f'{self.__class__.__name__}(pool_size={self.pool_size}, '
-                f'buffer_size={self.buffer_size}, '
-                f'embedding_dim={self.embedding_dim}, '
-                f'device={self._device})')
+    def extra_repr(self) -> str:
+        return (f'pool_size={self.pool_size}, buffer_size={self.buffer_size}, '
+                f'embedding_dim={self.embedding_dim}, device={self._device}')

@@ -220,22 +220,34 @@ class SparseTensor:
         return self.to("cuda" if device is None else device)
 
     # ------------------------------------------------------------------ edits (host-side graph prep)
+    # What a copy with other edge values may share with its source: sizes, index arrays and
+    # everything derived from the STRUCTURE alone.  Everything that holds values (transposed
+    # CSR, uploaded copies, the in-batch view, the value-less view) is rebuilt on demand.
+    _STRUCTURE_KEYS = ("_sizes", "_device", "_rowptr_i64", "_col_i64", "_rowptr_i32", "_col_i32",
+                       "_row", "_max_row_nnz", "_orders", "_in_place_cols", "_halo_plan")
+
     def set_value(self, value: Optional[Tensor], layout: Optional[str] = None) -> "SparseTensor":
         out = SparseTensor.__new__(SparseTensor)
-        out.__dict__.update(self.__dict__)
+        for k in self._STRUCTURE_KEYS:
+            if k in self.__dict__:
+                out.__dict__[k] = self.__dict__[k]
+        out._max_row_nnz = self.max_row_nnz() if self._host is not None else self._max_row_nnz
         out._value = value
         out._transposed = {}
-        out.__dict__.pop("_unweighted_view", None)
-        out._host = None if self._host is None else self._host.set_value(
-            None if value is None else value.cpu())
+        # a device copy with new values no longer mirrors its host original: its own arrays
+        # are the source of everything derived from now on (no device-to-host copy here)
+        out._host = None
         out.storage = _Storage(out)
         return out
 
     def set_value_(self, value: Optional[Tensor], layout: Optional[str] = None) -> "SparseTensor":
+        if self._host is not None:
+            self._max_row_nnz = self.max_row_nnz()
         self._value = value
         self._transposed = {}
-        if self._host is not None:
-            self._host = self._host.set_value(None if value is None else value.cpu())
+        self._host = None
+        for k in ("_in_batch_view", "_device_copies", "_unweighted_view"):
+            self.__dict__.pop(k, None)
         return self
 
     def set_diag(self, values: Optional[Tensor] = None) -> "SparseTensor":
@@ -305,19 +317,21 @@ class SparseTensor:
         columns below ``n_in_batch`` unchanged, column ``c`` above it becomes
         ``n_in_batch + halo_ids[c - n_in_batch]`` (int32, device; built once per adjacency
         and id vector)."""
-        # one entry: an adjacency belongs to one batch, i.e. one id vector
+        # Every array built here is kept for the life of the adjacency (and the id vector with
+        # it, so that its address cannot be handed to another tensor): a recorded HIP graph
+        # holds the address of the array it was recorded with.
         key = (halo_ids.data_ptr(), halo_ids.numel(), n_in_batch)
-        hit = self.__dict__.get("_in_place_cols")
-        if hit is None or hit[0] != key:
+        cache = self.__dict__.setdefault("_in_place_cols", {})
+        hit = cache.get(key)
+        if hit is None:
             if halo_ids.numel() < self._sizes[1] - n_in_batch:
                 raise ValueError("halo_ids does not cover the out-of-batch columns")
             col = self._col32().to(torch.int64)
             ids = halo_ids.to(device=col.device, dtype=torch.int64)
             moved = n_in_batch + ids[(col - n_in_batch).clamp_(min=0)] if ids.numel() else col
             out = torch.where(col < n_in_batch, col, moved).to(torch.int32)
-            hit = (key, out, halo_ids)    # the id vector is kept alive with its address
-            self._in_place_cols = hit
-        return hit[1]
+            hit = cache[key] = (out, halo_ids)
+        return hit[0]
 
     def row_order(self) -> Tensor:
         """Rows by descending length, on the device.  Built on the host when the adjacency is

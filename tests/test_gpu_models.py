@@ -50,7 +50,7 @@ def test_model_paths_tables_on_host_with_staging_pools(name, pool_size, dev):
     mc.check_incagg_forward(name, model, data, ptr, dev)
     mc.check_training_step(name, model, data, ptr, dev, vr=False)
     mc.check_training_step(name, model, data, ptr, dev, vr=True)
-    assert len(model.pool._pull_queue) == 0 and len(model.pool_ag._pull_queue) == 0
+    assert len(model.pool.pending) == 0 and len(model.pool_ag.pending) == 0
     _lib.check_device_errors()
 
 

@@ -99,7 +99,7 @@ def test_pool_queue_discipline_on_device(dev, zero_copy):
         idx = torch.from_numpy(rng.permutation(n)[:200 + k].astype(np.int64))
         reqs.append((off, cnt, idx))
         pool.async_pull(table, off, cnt, idx)
-    assert len(pool._pull_queue) == 5
+    assert len(pool.pending) == 5
     for k, (off, cnt, idx) in enumerate(reqs):
         total = int(cnt.sum()) + idx.numel()
         got = pool.synchronize_pull()[:total].clone()
@@ -107,7 +107,7 @@ def test_pool_queue_discipline_on_device(dev, zero_copy):
         cp.read_async(table.numpy(), off.numpy(), cnt.numpy(), idx.numpy(), want)
         assert np.array_equal(got.cpu().numpy(), want), f"pull {k}"
         pool.free_pull()
-    assert pool._pull_queue == [] and pool._pull_index == -1
+    assert pool.pending == [] and pool.last_pull_slot == -1
 
     # pushes: slots recycle, the pinned table ends up with every chunk
     dst = torch.zeros(n, w).pin_memory()

@@ -107,9 +107,8 @@ def test_pool_queue_matches_reference_model(monkeypatch):
         def synchronize(self): pass
 
     p = pool_mod.AsyncIOPool(pool_size=2, buffer_size=8, embedding_dim=4)
-    monkeypatch.setattr(p, "_pull_stream", lambda idx: FakeStream())
-    monkeypatch.setattr(p, "_async_pull", lambda idx, src, o, c, index: log.append(("launch_pull", idx, src)))
-    monkeypatch.setattr(p, "synchronize_pull", lambda: log.append(("sync_pull", p._pull_queue[0][0], p._pull_queue[0][1])) or p._pull_queue[0][0])
+    monkeypatch.setattr(p, "_start_pull", lambda req: log.append(("launch_pull", req.slot, req.src)))
+    monkeypatch.setattr(p, "synchronize_pull", lambda: log.append(("sync_pull", p.pending[0].slot, p.pending[0].src)) or p.pending[0].slot)
     m = PoolModel(2)
     script = ["pull a", "pull b", "pull c", "sync", "free", "pull d", "sync", "free", "sync", "free",
               "pull e", "sync", "free", "sync", "free"]
@@ -121,8 +120,8 @@ def test_pool_queue_matches_reference_model(monkeypatch):
             assert p.synchronize_pull() == m.synchronize_pull()
         else:
             p.free_pull(); m.free_pull()
-        assert [q[0] for q in p._pull_queue] == [q[0] for q in m.queue]
-        assert p._pull_index == m.pull_index
+        assert [q.slot for q in p.pending] == [q[0] for q in m.queue]
+        assert p.last_pull_slot == m.pull_index
     assert log == m.log
 
 
