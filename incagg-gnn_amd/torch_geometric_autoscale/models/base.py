@@ -401,6 +401,8 @@ class ScalableGNN(torch.nn.Module):
         # out-of-batch rows of the current layer input (never concatenated): pulled rows, or
         # the whole table plus the row ids when they are read in place
         halo = halo_ids = None
+        # node ids where the tables live: one upload per batch object, not one per layer and step
+        nid = None if n_id is None else _ids_on(adj_t, n_id, self.emb_device)
         for i in range(self.num_layers):
             x = self._layer_input(i, x)
             if not use_aggregation:
@@ -422,7 +424,6 @@ class ScalableGNN(torch.nn.Module):
                     h = self._update(i, agg, x, state)
                 self._release_halo()
             if i < self.num_layers - 1:
-                nid = None if n_id is None else n_id.to(self.emb_device)
                 if use_aggregation:
                     x, halo, halo_ids = self._push_and_pull_split(self.histories[i + 1], h,
                                                                   batch_size, nid, offset, count)
@@ -535,11 +536,7 @@ class ScalableGNN(torch.nn.Module):
                     and _same_device(self.emb_device, self.device))
 
         def ids_on_device(data, n_id):     # one upload per (static) evaluation batch
-            cached = data.__dict__.get("_n_id_dev")
-            if cached is None or cached.device != self.device or cached.numel() != n_id.numel():
-                cached = n_id.to(self.device)
-                data.__dict__["_n_id_dev"] = cached   # beside the attribute store, not in it
-            return cached
+            return _ids_on(data.adj_t, n_id, self.device)
 
         def run_layer(i, x, adj_t, batch_size, offset, count, state, halo=None, halo_ids=None):
             offset = self._local(offset)
@@ -618,6 +615,20 @@ class ScalableGNN(torch.nn.Module):
         ``histories_ag`` (M_ag) (e.g. models/gcn2.py:433-507).  The aggregate of a
         layer's input is computed once and used for M_ag and for the layer itself."""
         return self._sweep(loader, use_aggregation, with_aggregates=True)
+
+
+def _ids_on(holder, n_id: Tensor, device) -> Tensor:
+    """``n_id`` on ``device``, uploaded once per (holder, id tensor) and kept on the holder --
+    the batch's adjacency -- together with the tensor it was copied from, so that every step
+    over the same batch object hands the kernels the same device array."""
+    device = torch.device(device)
+    if n_id.device == device or (n_id.is_cuda and device.type == "cuda" and device.index is None):
+        return n_id
+    kept = holder.__dict__.setdefault("_ids_on_device", {})
+    hit = kept.get(device)
+    if hit is None or hit[0] is not n_id or hit[2] != n_id._version:
+        hit = kept[device] = (n_id, n_id.to(device), n_id._version)
+    return hit[1]
 
 
 def _same_device(a, b) -> bool:

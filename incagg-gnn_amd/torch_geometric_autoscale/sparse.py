@@ -224,7 +224,8 @@ class SparseTensor:
     # everything derived from the STRUCTURE alone.  Everything that holds values (transposed
     # CSR, uploaded copies, the in-batch view, the value-less view) is rebuilt on demand.
     _STRUCTURE_KEYS = ("_sizes", "_device", "_rowptr_i64", "_col_i64", "_rowptr_i32", "_col_i32",
-                       "_row", "_max_row_nnz", "_orders", "_in_place_cols", "_halo_plan")
+                       "_row", "_max_row_nnz", "_orders", "_in_place_cols", "_halo_plan",
+                       "_ids_on_device")
 
     def set_value(self, value: Optional[Tensor], layout: Optional[str] = None) -> "SparseTensor":
         out = SparseTensor.__new__(SparseTensor)
@@ -317,21 +318,30 @@ class SparseTensor:
         columns below ``n_in_batch`` unchanged, column ``c`` above it becomes
         ``n_in_batch + halo_ids[c - n_in_batch]`` (int32, device; built once per adjacency
         and id vector)."""
-        # Every array built here is kept for the life of the adjacency (and the id vector with
-        # it, so that its address cannot be handed to another tensor): a recorded HIP graph
-        # holds the address of the array it was recorded with.
-        key = (halo_ids.data_ptr(), halo_ids.numel(), n_in_batch)
+        # ONE array per (id count, batch size), kept for the life of the adjacency and only
+        # ever rewritten in place: a recorded HIP graph holds the address of the array it was
+        # recorded with, so the array is never freed and never replaced.  The id vector it was
+        # filled from is kept too (its address then cannot be handed to another tensor); a call
+        # with another id vector refills the same array.
+        key = (halo_ids.numel(), n_in_batch)
         cache = self.__dict__.setdefault("_in_place_cols", {})
         hit = cache.get(key)
+        stamp = (halo_ids.data_ptr(), halo_ids._version)
+        if hit is not None and hit[1] == stamp:
+            return hit[0]
+        if halo_ids.numel() < self._sizes[1] - n_in_batch:
+            raise ValueError("halo_ids does not cover the out-of-batch columns")
+        col = self._col32().to(torch.int64)
+        ids = halo_ids.to(device=col.device, dtype=torch.int64)
+        moved = n_in_batch + ids[(col - n_in_batch).clamp_(min=0)] if ids.numel() else col
+        fresh = torch.where(col < n_in_batch, col, moved).to(torch.int32)
         if hit is None:
-            if halo_ids.numel() < self._sizes[1] - n_in_batch:
-                raise ValueError("halo_ids does not cover the out-of-batch columns")
-            col = self._col32().to(torch.int64)
-            ids = halo_ids.to(device=col.device, dtype=torch.int64)
-            moved = n_in_batch + ids[(col - n_in_batch).clamp_(min=0)] if ids.numel() else col
-            out = torch.where(col < n_in_batch, col, moved).to(torch.int32)
-            hit = cache[key] = (out, halo_ids)
-        return hit[0]
+            out = fresh
+        else:
+            out = hit[0]
+            out.copy_(fresh)
+        cache[key] = (out, stamp, halo_ids)
+        return out
 
     def row_order(self) -> Tensor:
         """Rows by descending length, on the device.  Built on the host when the adjacency is
