@@ -6,7 +6,7 @@ import torch
 
 from oracle import model_oracle as mo
 
-TOL = dict(rtol=2e-4, atol=2e-4)   # fp32 chains of L layers against the fp32 numpy restatement
+TOL = dict(rtol=1e-4, atol=1e-4)   # the fp32 bar per embedding, held over chains of up to 4 layers
 
 
 def make_graph(n=1400, parts=6, f_in=24, n_cls=5, seed=0):
@@ -131,6 +131,40 @@ def check_push_pull_forward(name, model, data, ptr, want, device):
             f"{name}: pulled vs in-place halo rows differ"
 
 
+def check_ablation_modes(name, model, data, ptr, device):
+    """The two ablation switches of the push/pull forward (models/gcn.py:115-141,167-193):
+    ``aggregate_combined=False`` aggregates over in-batch edges only -- the model evaluated on
+    the subgraph induced by the batch -- and ``use_aggregation=False`` replaces every
+    aggregation by the identity (the layers degrade to an MLP over the batch rows)."""
+    from torch_geometric_autoscale.loader import partition_batch
+    case = MODEL_CASES[name]
+    model.eval()
+    sd = numpy_state(model)
+    for parts in ([2], [5, 0]):
+        sub = partition_batch(data, ptr, parts)
+        b = sub.batch_size
+        rowptr, col, val = (t.numpy() for t in sub.data.adj_t.csr())
+        keep = col < b
+        row = np.repeat(np.arange(b), np.diff(rowptr))
+        ib_rowptr = np.zeros(b + 1, dtype=np.int64)
+        np.cumsum(np.bincount(row[keep], minlength=b), out=ib_rowptr[1:])
+        x_b = sub.data.x[:b].numpy()
+        _, _, want_ib = mo.full_graph(case["kind"], sd, case["cfg"], ib_rowptr, col[keep],
+                                      val[keep], x_b)
+        eye = np.arange(b + 1, dtype=np.int64)
+        _, _, want_mlp = mo.full_graph(case["kind"], sd, case["cfg"], eye, eye[:b],
+                                       np.ones(b, dtype=np.float32), x_b)
+        args = (sub.data.x.to(device), sub.data.adj_t.to(device), b, sub.n_id, sub.offset, sub.count)
+        with torch.no_grad():
+            got_ib = model(*args, aggregate_combined=False)["out"]
+            got_mlp = model(*args, use_aggregation=False)["out"]
+        assert got_ib.size(0) == b and got_mlp.size(0) == b
+        np.testing.assert_allclose(got_ib.cpu().numpy(), want_ib, **TOL,
+                                   err_msg=f"{name}: in-batch edges only, parts {parts}")
+        np.testing.assert_allclose(got_mlp.cpu().numpy(), want_mlp, **TOL,
+                                   err_msg=f"{name}: no aggregation, parts {parts}")
+
+
 def check_incagg_forward(name, model, data, ptr, device):
     """Incremental-aggregation forward against the explicit formula with the table contents,
     after the weights moved away from the ones the tables were computed with."""
@@ -175,4 +209,4 @@ def check_training_step(name, model, data, ptr, device, vr):
     assert grads and all(torch.isfinite(g).all() for g in grads)
     assert any(float(g.abs().sum()) > 0 for g in grads)
     opt.step()
-    return float(loss)
+    return float(loss.detach())

@@ -297,3 +297,130 @@ def test_full_size_properties(ops, dev, variant):
     t2 = table.clone()
     ops.scatter_rows(t2, n_id, rows)
     assert torch.equal(t2, table)
+
+
+# ---------------------------------------------------------------- split source / in-place rows
+def _straddling_batch(rng, b, m, hubs):
+    """[b, m] adjacency whose hub rows reference columns on both sides of column b."""
+    rowptr, col, val = random_csr(rng, b, m, 11, hubs=hubs, empty_rows=(1, b - 1))
+    for r in dict(hubs):
+        cs = col[rowptr[r]:rowptr[r + 1]]
+        assert cs.min() < b <= cs.max(), "hub row must straddle the split"
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("width", [256, 128, 41])
+@pytest.mark.parametrize("form", ["pulled", "table"])
+def test_spmm_split_source_matches_oracle(ops, dev, width, form, variant):
+    """The aggregation as the push/pull step launches it: source rows < B from the fresh batch
+    matrix, the rest either from a pulled matrix or in place from a whole History table
+    through rewritten column ids (B + global id); hub rows (> 128 and > 1 024 edges) on both
+    sides of the split.  Oracle: the fp64 row loop on the concatenated source."""
+    from torch_geometric_autoscale import _lib
+    rng = np.random.default_rng(width * 3 + (form == "table"))
+    b, m, n_table, table_w = 400, 3000, 5000, 256
+    rowptr, col, val = _straddling_batch(rng, b, m, {3: 140, 50: 700, 51: 1500, 399: 2900})
+    halo_ids = rng.permutation(n_table)[:m - b].astype(np.int64)
+    x = rng.standard_normal((b, width)).astype(np.float32)
+    table = rng.standard_normal((n_table, table_w)).astype(np.float32)
+    src = np.concatenate([x, table[halo_ids, :width]])
+    rp, c, v = _dev_csr(rowptr, col, val, dev)
+    xd = torch.from_numpy(x).to(dev)
+    td = torch.from_numpy(table).to(dev)
+    for reduce in ("sum", "mean"):
+        y64 = cp.spmm_f64(rowptr, col, val if reduce == "sum" else None, src, reduce)
+        vv = v if reduce == "sum" else None
+        if form == "pulled":
+            halo = ops.gather_rows(td, torch.from_numpy(halo_ids).to(dev))[:, :width]
+            y = ops.spmm_csr(rp, c, vv, xd, m, reduce, x_halo=halo, row_order=_ro(variant, rp),
+                             max_row_nnz=2900)
+        else:
+            cip = np.where(col < b, col, b + halo_ids[np.maximum(col - b, 0)]).astype(np.int32)
+            y = ops.spmm_csr(rp, torch.from_numpy(cip).to(dev), vv, xd, b + n_table, reduce,
+                             x_halo=td[:, :width], row_order=_ro(variant, rp), max_row_nnz=2900)
+        tol = tolerance(y64) + 1e-6 * np.sqrt(2900)
+        err = np.abs(y.cpu().numpy() - y64)
+        assert np.all(err <= tol), f"{form} {reduce}: max err {err.max()}"
+    _lib.check_device_errors()
+
+
+def test_spmm_in_place_through_sparse_tensor(dev):
+    """spmm(adj, x, x_halo=table, halo_ids=...) builds the rewritten column ids itself and
+    agrees with the pulled form, also after the same adjacency is called with another (equal)
+    id tensor: the id array is refilled in place, never replaced."""
+    import torch_geometric_autoscale as tga
+    rng = np.random.default_rng(77)
+    b, m, n_table, w = 300, 1500, 4000, 256
+    rowptr, col, val = _straddling_batch(rng, b, m, {7: 600, 100: 1400})
+    adj = tga.SparseTensor(rowptr=torch.from_numpy(rowptr), col=torch.from_numpy(col),
+                           value=torch.from_numpy(val), sparse_sizes=(b, m), is_sorted=True).to(dev)
+    halo_ids = torch.from_numpy(rng.permutation(n_table)[:m - b].astype(np.int64)).to(dev)
+    x = torch.randn(b, w, device=dev)
+    table = torch.randn(n_table, w, device=dev)
+    want = tga.spmm(adj, x, x_halo=table[halo_ids])
+    got = tga.spmm(adj, x, x_halo=table, halo_ids=halo_ids)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    first = adj.col_in_place(halo_ids, b)
+    again = adj.col_in_place(halo_ids.clone(), b)
+    assert again.data_ptr() == first.data_ptr()
+    other = halo_ids.flip(0).contiguous()
+    got2 = tga.spmm(adj, x, x_halo=table, halo_ids=other)
+    assert adj.col_in_place(other, b).data_ptr() == first.data_ptr()
+    assert torch.allclose(got2, tga.spmm(adj, x, x_halo=table[other]), rtol=1e-5, atol=1e-5)
+
+
+def test_spmm_single_source_beyond_4gib(ops, dev, variant):
+    """One source matrix of more than 4 GiB: row offsets need 64 bits in every kernel variant.
+    The oracle runs on the referenced rows only."""
+    width = 256
+    n_cols = (1 << 32) // (width * 4) + 70000         # ~4.37 GiB of fp32 rows
+    rng = np.random.default_rng(4)
+    n_rows = 200
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, 15, hubs={2: 300, 9: 1100})
+    col[-1] = n_cols - 1                               # the very last row is referenced
+    col[rowptr[2]:rowptr[3]] = np.sort(rng.choice(np.arange(n_cols - 5000, n_cols - 1),
+                                                  size=300, replace=False))
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n_cols, width, device=dev, generator=g)
+    uniq, inv = np.unique(col, return_inverse=True)
+    xs = x[torch.from_numpy(uniq).to(dev)].cpu().numpy()
+    y64 = cp.spmm_f64(rowptr, inv.astype(np.int64), val, xs)
+    rp, c, v = _dev_csr(rowptr, col, val, dev)
+    y = ops.spmm_csr(rp, c, v, x, n_cols, row_order=_ro(variant, rp))
+    tol = tolerance(y64) + 1e-6 * np.sqrt(1100)
+    assert np.all(np.abs(y.cpu().numpy() - y64) <= tol)
+    del x
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_transposed_windows_width_256(dev, reduce, variant):
+    """The two backward launches of a push/pull step at the headline width: the [M, B]
+    transposed adjacency (layer 0) and its [B, B] window of in-batch columns (other layers,
+    source split in fresh + pulled rows), each with its own degree order."""
+    import torch_geometric_autoscale as tga
+    rng = np.random.default_rng(8 + (reduce == "mean"))
+    b, m, w = 500, 2600, 256
+    rowptr, col, val = _straddling_batch(rng, b, m, {0: 900, 250: 2000})
+    # columns referenced by hundreds of rows: long rows of the transposed matrix
+    for r in range(0, b, 2):
+        if rowptr[r + 1] > rowptr[r]:
+            col[rowptr[r]] = 0 if 0 not in col[rowptr[r]:rowptr[r + 1]] else col[rowptr[r]]
+    for r in range(b):
+        col[rowptr[r]:rowptr[r + 1]].sort()
+    weighted = reduce == "sum"
+    adj = tga.SparseTensor(rowptr=torch.from_numpy(rowptr), col=torch.from_numpy(col),
+                           value=torch.from_numpy(val) if weighted else None,
+                           sparse_sizes=(b, m), is_sorted=True).to(dev)
+    v_or = val if weighted else None
+    dy = torch.randn(b, w, device=dev)
+    want = cp.spmm_t(rowptr, col, v_or, dy.cpu().numpy(), m, reduce)
+    # [M, B]: gradient for every source row
+    x = torch.randn(m, w, device=dev, requires_grad=True)
+    tga.spmm(adj, x, reduce).backward(dy)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # [B, B] window: only the fresh rows get a gradient
+    xb = torch.randn(b, w, device=dev, requires_grad=True)
+    halo = torch.randn(m - b, w, device=dev)
+    tga.spmm(adj, xb, reduce, x_halo=halo).backward(dy)
+    np.testing.assert_allclose(xb.grad.cpu().numpy(), want[:b], rtol=1e-4, atol=1e-4)

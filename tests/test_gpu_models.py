@@ -27,6 +27,7 @@ def test_model_paths_tables_in_hbm(name, dev):
     loader, want = mc.check_refresh_sweep(name, model, data, ptr)
     mc.check_push_pull_forward(name, model, data, ptr, want, dev)
     mc.check_plain_sweep(name, model, data, ptr)
+    mc.check_ablation_modes(name, model, data, ptr, dev)
     mc.check_incagg_forward(name, model, data, ptr, dev)
     mc.check_training_step(name, model, data, ptr, dev, vr=False)
     mc.check_training_step(name, model, data, ptr, dev, vr=True)

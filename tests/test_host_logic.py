@@ -178,6 +178,16 @@ def test_neighbor_sampling_and_edge_dropout():
     weighted = adj.fill_value(1.0)
     w = tga.dropout(weighted, 0.5).storage.value()
     assert w.numel() == adj.nnz() and set(w.unique().tolist()) == {0.0, 2.0}
+    # an adjacency with dropped weights does not inherit value-carrying views of its source:
+    # the in-batch view (models/gcn.py:117-126) of the dropped matrix holds the dropped weights
+    from torch_geometric_autoscale.models.base import in_batch_columns
+    first = in_batch_columns(weighted, 300)           # cached on the source
+    dropped = tga.dropout(weighted, 0.5)
+    view = in_batch_columns(dropped, 300)
+    assert view is not first
+    _, c, v = dropped.coo()[0], dropped.coo()[1], dropped.coo()[2]
+    assert torch.equal(view.storage.value(), v[c < 300])
+    assert set(first.storage.value().unique().tolist()) == {1.0}
 
 
 def test_batched_gcn2_terms_and_fused_embed_have_the_plain_gradients():

@@ -18,6 +18,7 @@ def test_model_paths_on_cpu(name):
         loader, want = mc.check_refresh_sweep(name, model, data, ptr)
         mc.check_push_pull_forward(name, model, data, ptr, want, torch.device("cpu"))
         mc.check_plain_sweep(name, model, data, ptr)
+        mc.check_ablation_modes(name, model, data, ptr, torch.device("cpu"))
         mc.check_incagg_forward(name, model, data, ptr, torch.device("cpu"))
         mc.check_training_step(name, model, data, ptr, torch.device("cpu"), vr=False)
         mc.check_training_step(name, model, data, ptr, torch.device("cpu"), vr=True)
