@@ -20,6 +20,15 @@ from .data import Data
 from .sparse import SparseTensor
 
 
+def _relabel_one_hop(*args):
+    """Bound at call time to the registered operator (loader.py:23 of the reference)."""
+    return torch.ops.torch_geometric_autoscale.relabel_one_hop(*args)
+
+
+def _relabel_one_hop_within_batch(*args):
+    return torch.ops.torch_geometric_autoscale.relabel_one_hop_within_batch(*args)
+
+
 class SubData(NamedTuple):
     data: Data
     batch_size: int
@@ -67,7 +76,7 @@ def partition_batch(data: Data, ptr: Tensor, part_ids, in_batch_only: bool = Fal
     offset = ptr[batch_id]
     count = ptr[batch_id + 1] - offset
     rowptr, col, value = data.adj_t.csr()
-    fn = ops.relabel_one_hop_within_batch if in_batch_only else ops.relabel_one_hop
+    fn = _relabel_one_hop_within_batch if in_batch_only else _relabel_one_hop
     batch_size = n_id.numel()
     rowptr, col, value, n_id = fn(rowptr, col, value, n_id, bipartite)
     adj_t = SparseTensor(rowptr=rowptr, col=col, value=value,
@@ -206,7 +215,7 @@ class SubgraphLoader(DataLoader):
         """Batch rows plus their full one-hop halo (loader.py:172-192)."""
         n_id, batch_size, offset, count = self._batch_header(batches)
         rowptr, col, value = self.data.adj_t.csr()
-        rowptr, col, value, n_id = ops.relabel_one_hop(rowptr, col, value, n_id, self.bipartite)
+        rowptr, col, value, n_id = _relabel_one_hop(rowptr, col, value, n_id, self.bipartite)
         return self._finish(rowptr, col, value, n_id, batch_size, offset, count)
 
     def compute_subgraph_IB(self, batches: List[Tuple[int, Tensor]]) -> SubData:
@@ -214,7 +223,7 @@ class SubgraphLoader(DataLoader):
         path (loader.py:194-214)."""
         n_id, batch_size, offset, count = self._batch_header(batches)
         rowptr, col, value = self.data.adj_t.csr()
-        rowptr, col, value, n_id = ops.relabel_one_hop_within_batch(rowptr, col, value, n_id,
+        rowptr, col, value, n_id = _relabel_one_hop_within_batch(rowptr, col, value, n_id,
                                                                     self.bipartite)
         return self._finish(rowptr, col, value, n_id, batch_size, offset, count)
 
@@ -222,7 +231,7 @@ class SubgraphLoader(DataLoader):
         """One-hop batch with optional per-row neighbour sampling (loader.py:217-246)."""
         n_id, batch_size, offset, count = self._batch_header(batches)
         rowptr, col, value = self.data.adj_t.csr()
-        rowptr, col, value, n_id = ops.relabel_one_hop(rowptr, col, value, n_id, self.bipartite)
+        rowptr, col, value, n_id = _relabel_one_hop(rowptr, col, value, n_id, self.bipartite)
         if self.num_neighbors is not None and self.num_neighbors >= 0:
             adj_t = SparseTensor(rowptr=rowptr, col=col, value=value,
                                  sparse_sizes=(rowptr.numel() - 1, n_id.numel()), is_sorted=True)

@@ -524,11 +524,22 @@ def write_async(src: Tensor, offset: Tensor, count: Tensor, dst: Tensor) -> None
 _registered = None
 
 
+def torch_ops_defined() -> bool:
+    """True when the five operators already exist in this process (operator objects loaded by
+    the reference's own ``__init__``, or an earlier registration)."""
+    ns = torch.ops.torch_geometric_autoscale
+    try:
+        return all(hasattr(ns, n) for n in ("synchronize", "read_async", "write_async",
+                                            "relabel_one_hop", "relabel_one_hop_within_batch"))
+    except RuntimeError:
+        return False
+
+
 def register_torch_ops() -> bool:
     """Defines torch.ops.torch_geometric_autoscale.{synchronize, read_async, write_async,
     relabel_one_hop, relabel_one_hop_within_batch} with the reference's schemas."""
     global _registered
-    if _registered is not None:
+    if _registered is not None or torch_ops_defined():
         return True
     try:
         reg = torch.library.Library("torch_geometric_autoscale", "DEF")

@@ -21,7 +21,19 @@ from typing import Callable, List, NamedTuple, Optional
 import torch
 from torch import Tensor
 
-from . import ops
+from . import ops  # noqa: F401  (defines the operators when no operator object was loaded)
+
+
+class _Native:
+    """``torch.ops.torch_geometric_autoscale.{synchronize, read_async, write_async}``, bound at
+    call time like pool.py:10-12 of the reference binds them: whichever object registered the
+    operators (the loaded ``_async`` library, or the Python registration) is what runs."""
+
+    def __getattr__(self, name):
+        return getattr(torch.ops.torch_geometric_autoscale, name)
+
+
+_native = _Native()
 
 
 class _Pull(NamedTuple):
@@ -109,12 +121,12 @@ class AsyncIOPool(torch.nn.Module):
             kernel_gather = (self.zero_copy and index.numel() > 0 and src.is_pinned()
                              and src.dtype == torch.float32)
             if not kernel_gather:
-                ops.read_async(src, offset, count, index.cpu(), dst, slot.host_buffer())
+                _native.read_async(src, offset, count, index.cpu(), dst, slot.host_buffer())
                 return
             n_chunk_rows = 0 if count is None else int(count.sum())
             if n_chunk_rows + index.numel() > self.buffer_size:
                 raise RuntimeError("Buffer tensor size too small")
-            ops.read_async(src, offset, count, torch.empty(0, dtype=torch.int64), dst,
+            _native.read_async(src, offset, count, torch.empty(0, dtype=torch.int64), dst,
                            slot.host_buffer())
             ids = index.to(self._device, non_blocking=True)
             ops.gather_rows(src, ids, out=dst[n_chunk_rows:n_chunk_rows + index.numel()],
@@ -125,7 +137,7 @@ class AsyncIOPool(torch.nn.Module):
         """The device buffer of the OLDEST pending pull, usable on the current stream
         (pool.py:83-88).  It stays valid until :meth:`free_pull`."""
         slot = self._slots[self.pending[0].slot]
-        ops.synchronize()       # the worker has enqueued every copy of that pull
+        _native.synchronize()       # the worker has enqueued every copy of that pull
         torch.cuda.current_stream(self._device).wait_stream(slot.stream("pull"))
         return slot.device_buffer()
 
@@ -152,7 +164,7 @@ class AsyncIOPool(torch.nn.Module):
         stream = slot.stream("push")
         stream.wait_stream(torch.cuda.current_stream(self._device))   # src is complete first
         with torch.cuda.stream(stream):
-            ops.write_async(src, offset, count, dst)
+            _native.write_async(src, offset, count, dst)
         src.record_stream(stream)
 
     @torch.no_grad()
