@@ -127,16 +127,24 @@ class KernelClock:
 
 def pmc_traffic(args):
     """Fabric bytes per aggregation launch from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs of this very
-    command reduced by profiles/pmc_traffic.py, FETCH_SIZE doubled as gfx950 requires).  Counters cannot be read from inside
-    the process, so the figure is only reported for the workload it was measured on."""
+    (profiles/pmc_traffic_current.json: separate FETCH_SIZE and WRITE_SIZE runs of this very
+    command reduced by profiles/pmc_traffic.py, FETCH_SIZE doubled as gfx950 requires).
+    Counters cannot be read from inside the process, so the figure is only reported for the
+    workload it was measured on and only while the kernel source is the one it was measured
+    with (SHA-256 recorded next to it); otherwise null."""
+    import hashlib
     default = (args.dataset, args.parts, args.layers, args.hidden, args.scale, args.cross,
                args.mode) == ("products", 150, 8, 256, 1.0, 0.15, "gas")
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not default or not os.path.isfile(path):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_current.json")
+    src = os.path.join(ROOT, "incagg-gnn_amd", "csrc", "aggregate.hip")
+    if not default or not os.path.isfile(path) or not os.path.isfile(src):
         return None
     with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+        rec = json.load(f)
+    with open(src, "rb") as f:
+        if rec.get("kernel_source_sha256") != hashlib.sha256(f.read()).hexdigest():
+            return None
+    return rec["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(batches, layers, width, seconds):
@@ -435,7 +443,7 @@ def main():
             line["roofline"] = {
                 "bound": "hbm", "achieved": ks["algo_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ks["algo_GBps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(args),
-                "kernel": "spmm_grouped_kernel (+ spmm_sliced_hub_kernel), forward and transposed launches",
+                "kernel": "spmm_plan_kernel, forward and transposed launches (one launch per call)",
                 "avg_launch_ms": ks["avg_ms"], "launches": ks["launches"],
                 "algorithmic_bytes_per_launch": ks["algo_bytes_per_launch"],
                 "gather_bound_GBps": ks["gather_GBps"],

@@ -29,6 +29,9 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // Device address of the per-device "bad index seen" flag (see errors.hip).
 int error_flag_address(int **out);
 
+// Defaults of the aggregation plan builders (tunable, see incagg_set_tuning).
+void plan_defaults(int *hub_threshold, int *segment_edges);
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace incagg

@@ -1,0 +1,244 @@
+// Work plan of the aggregation: a pure function of the row pointers, built once per adjacency
+// (and once per window of a transposed adjacency) at batch construction, on the host or on the
+// GPU.  Integer work; both builders produce the same arrays, element for element.
+//
+//   order[n_rows]      rows by descending length, ties in ascending row id (stable)
+//   n_hub              rows longer than hub_threshold: the first n_hub entries of `order`
+//   items[2 * n_items] (row, segment) pairs, rows in the order above, segments ascending;
+//                      a segment is segment_edges edges (the last one shorter)
+//   multi_rows[n_multi] the rows with more than one segment
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <numeric>
+#include <vector>
+
+namespace incagg {
+
+constexpr int kBlock = 256;
+
+static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+static inline unsigned grid_for(long long n) { return (unsigned)std::max<long long>(1, (n + kBlock - 1) / kBlock); }
+
+struct PlanStatus {
+  int n_hub;
+  int n_items;
+  int n_multi;
+  int error;  // 1: negative row length, 2: capacity exceeded
+};
+
+__global__ __launch_bounds__(kBlock) void plan_degrees_kernel(const int *rowptr, int n_rows,
+                                                             int *deg, int *ids, PlanStatus *st) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_rows) return;
+  int d = rowptr[i + 1] - rowptr[i];
+  if (d < 0) {
+    st->error = 1;
+    d = 0;
+  }
+  deg[i] = d;
+  ids[i] = i;
+}
+
+// Over the sorted positions: segments and "several segments" flag of every position.
+__global__ __launch_bounds__(kBlock) void plan_segments_kernel(const int *deg_sorted, int n_rows,
+                                                              int hub_threshold, int seg,
+                                                              int *nseg, int *multi) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n_rows) return;
+  const int d = deg_sorted[j];
+  const int k = d > hub_threshold ? (d + seg - 1) / seg : 0;
+  nseg[j] = k;
+  multi[j] = k > 1 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void plan_fill_kernel(const int *order, const int *deg_sorted,
+                                                          const int *nseg, const int *item_off,
+                                                          const int *multi_off, int n_rows,
+                                                          int hub_threshold, long long items_cap,
+                                                          long long multi_cap, int2 *items,
+                                                          int *multi_rows, PlanStatus *st) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n_rows) return;
+  const int k = nseg[j];
+  if (j == n_rows - 1) {  // totals: exclusive sums + the last element
+    st->n_items = item_off[j] + k;
+    st->n_multi = multi_off[j] + (k > 1 ? 1 : 0);
+  }
+  // sorted descending: the long rows are a prefix, its length is the first position whose
+  // successor (or itself) is short
+  if (deg_sorted[j] > hub_threshold && (j == n_rows - 1 || deg_sorted[j + 1] <= hub_threshold))
+    st->n_hub = j + 1;
+  if (k == 0) return;
+  const int row = order[j];
+  const long long base = item_off[j];
+  if (base + k > items_cap) {
+    st->error = 2;
+    return;
+  }
+  for (int s = 0; s < k; s++) items[base + s] = make_int2(row, s);
+  if (k > 1) {
+    if (multi_off[j] >= multi_cap) {
+      st->error = 2;
+      return;
+    }
+    multi_rows[multi_off[j]] = row;
+  }
+}
+
+static int resolve(int32_t &hub_threshold, int32_t &segment_edges) {
+  int t = 0, s = 0;
+  plan_defaults(&t, &s);
+  if (hub_threshold <= 0) hub_threshold = t;
+  if (segment_edges <= 0) segment_edges = s;
+  INCAGG_REQUIRE(segment_edges % 64 == 0, "segment_edges %d is not a multiple of 64", segment_edges);
+  return INCAGG_OK;
+}
+
+}  // namespace incagg
+
+using namespace incagg;
+
+extern "C" int incagg_spmm_plan_defaults(int32_t *hub_threshold, int32_t *segment_edges) {
+  INCAGG_REQUIRE(hub_threshold && segment_edges, "null output");
+  int t = 0, s = 0;
+  plan_defaults(&t, &s);
+  *hub_threshold = t;
+  *segment_edges = s;
+  return INCAGG_OK;
+}
+
+extern "C" int64_t incagg_spmm_plan_items_bound(int64_t n_rows, int64_t nnz, int32_t hub_threshold,
+                                                int32_t segment_edges) {
+  if (n_rows < 0 || nnz < 0) return fail(INCAGG_E_INVALID, "negative size");
+  int rc = resolve(hub_threshold, segment_edges);
+  if (rc) return rc;
+  // every long row has more than hub_threshold edges and ceil(len / segment) <= 1 + len / segment
+  return std::min<int64_t>(n_rows, nnz / ((int64_t)hub_threshold + 1)) + nnz / segment_edges;
+}
+
+extern "C" int incagg_spmm_plan_host(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
+                                     int32_t segment_edges, int32_t *order, int32_t *items,
+                                     int64_t items_cap, int32_t *multi_rows, int64_t multi_cap,
+                                     int64_t *counts) {
+  INCAGG_REQUIRE(counts != nullptr, "null counts");
+  INCAGG_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 64, "row count out of range");
+  int rc = resolve(hub_threshold, segment_edges);
+  if (rc) return rc;
+  counts[0] = counts[1] = counts[2] = 0;
+  counts[3] = hub_threshold;
+  counts[4] = segment_edges;
+  if (n_rows == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(rowptr && order, "null rowptr or order");
+  for (int64_t i = 0; i < n_rows; i++)
+    if (rowptr[i + 1] < rowptr[i]) return fail(INCAGG_E_INVALID, "row pointers decrease at row %lld", (long long)i);
+  std::iota(order, order + n_rows, 0);
+  std::stable_sort(order, order + n_rows, [&](int32_t a, int32_t b) {
+    return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b];
+  });
+  int64_t n_hub = 0, n_items = 0, n_multi = 0;
+  for (int64_t j = 0; j < n_rows; j++) {
+    const int32_t row = order[j];
+    const int64_t d = (int64_t)rowptr[row + 1] - rowptr[row];
+    if (d <= hub_threshold) break;
+    n_hub++;
+    const int64_t k = (d + segment_edges - 1) / segment_edges;
+    if (n_items + k > items_cap || !items)
+      return fail(INCAGG_E_INVALID, "items capacity %lld too small", (long long)items_cap);
+    for (int64_t s = 0; s < k; s++) {
+      items[2 * (n_items + s)] = row;
+      items[2 * (n_items + s) + 1] = (int32_t)s;
+    }
+    n_items += k;
+    if (k > 1) {
+      if (n_multi >= multi_cap || !multi_rows)
+        return fail(INCAGG_E_INVALID, "multi_rows capacity %lld too small", (long long)multi_cap);
+      multi_rows[n_multi++] = row;
+    }
+  }
+  counts[0] = n_hub;
+  counts[1] = n_items;
+  counts[2] = n_multi;
+  return INCAGG_OK;
+}
+
+extern "C" int64_t incagg_spmm_plan_device_scratch_bytes(int64_t n_rows) {
+  if (n_rows < 0 || n_rows >= INT_MAX - 64) return fail(INCAGG_E_INVALID, "row count out of range");
+  const int n = (int)std::max<int64_t>(n_rows, 1);
+  size_t sort = 0, scan = 0;
+  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort, (int *)nullptr, (int *)nullptr,
+                                                     (int *)nullptr, (int *)nullptr, n);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (int *)nullptr, (int *)nullptr, n);
+  return (int64_t)(up256(sizeof(PlanStatus)) + 7 * up256(sizeof(int) * (size_t)n) +
+                   up256(std::max(sort, scan)));
+}
+
+extern "C" int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
+                                       int32_t segment_edges, void *scratch, int64_t scratch_bytes,
+                                       int32_t *order, int32_t *items, int64_t items_cap,
+                                       int32_t *multi_rows, int64_t multi_cap, int64_t *counts,
+                                       void *stream_) {
+  INCAGG_REQUIRE(counts != nullptr, "null counts");
+  INCAGG_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 64, "row count out of range");
+  int rc = resolve(hub_threshold, segment_edges);
+  if (rc) return rc;
+  counts[0] = counts[1] = counts[2] = 0;
+  counts[3] = hub_threshold;
+  counts[4] = segment_edges;
+  if (n_rows == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(rowptr && order, "null rowptr or order");
+  INCAGG_REQUIRE(items_cap >= 0 && multi_cap >= 0 && (items_cap == 0 || items) &&
+                     (multi_cap == 0 || multi_rows), "bad capacities");
+  const int64_t need = incagg_spmm_plan_device_scratch_bytes(n_rows);
+  INCAGG_REQUIRE(scratch && scratch_bytes >= need, "scratch too small: %lld < %lld",
+                 (long long)scratch_bytes, (long long)need);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int n = (int)n_rows;
+  char *base = static_cast<char *>(scratch);
+  const size_t e = up256(sizeof(int) * (size_t)n);
+  PlanStatus *st = reinterpret_cast<PlanStatus *>(base);
+  base += up256(sizeof(PlanStatus));
+  int *deg = reinterpret_cast<int *>(base);
+  int *ids = reinterpret_cast<int *>(base + e);
+  int *deg_sorted = reinterpret_cast<int *>(base + 2 * e);
+  int *nseg = reinterpret_cast<int *>(base + 3 * e);
+  int *multi = reinterpret_cast<int *>(base + 4 * e);
+  int *item_off = reinterpret_cast<int *>(base + 5 * e);
+  int *multi_off = reinterpret_cast<int *>(base + 6 * e);
+  void *cub = base + 7 * e;
+  const size_t cub_bytes = (size_t)scratch_bytes - (size_t)(static_cast<char *>(cub) - static_cast<char *>(scratch));
+
+  INCAGG_HIP_TRY(hipMemsetAsync(st, 0, sizeof(PlanStatus), stream));
+  const dim3 grid(grid_for(n)), block(kBlock);
+  hipLaunchKernelGGL(plan_degrees_kernel, grid, block, 0, stream, rowptr, n, deg, ids, st);
+  INCAGG_HIP_TRY(hipGetLastError());
+  // radix sort, descending and stable: ties keep ascending row ids, like the host builder
+  size_t tmp = cub_bytes;
+  INCAGG_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(cub, tmp, deg, deg_sorted, ids, order, n, 0,
+                                                              32, stream));
+  hipLaunchKernelGGL(plan_segments_kernel, grid, block, 0, stream, deg_sorted, n, hub_threshold,
+                     segment_edges, nseg, multi);
+  INCAGG_HIP_TRY(hipGetLastError());
+  tmp = cub_bytes;
+  INCAGG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, tmp, nseg, item_off, n, stream));
+  tmp = cub_bytes;
+  INCAGG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, tmp, multi, multi_off, n, stream));
+  hipLaunchKernelGGL(plan_fill_kernel, grid, block, 0, stream, order, deg_sorted, nseg, item_off,
+                     multi_off, n, hub_threshold, (long long)items_cap, (long long)multi_cap,
+                     reinterpret_cast<int2 *>(items), multi_rows, st);
+  INCAGG_HIP_TRY(hipGetLastError());
+  PlanStatus host{};
+  INCAGG_HIP_TRY(hipMemcpyAsync(&host, st, sizeof(PlanStatus), hipMemcpyDeviceToHost, stream));
+  INCAGG_HIP_TRY(hipStreamSynchronize(stream));
+  if (host.error == 1) return fail(INCAGG_E_INVALID, "row pointers decrease");
+  if (host.error == 2)
+    return fail(INCAGG_E_INVALID, "plan does not fit the capacities (items %lld, multi %lld)",
+                (long long)items_cap, (long long)multi_cap);
+  counts[0] = host.n_hub;
+  counts[1] = host.n_items;
+  counts[2] = host.n_multi;
+  return INCAGG_OK;
+}

@@ -20,10 +20,16 @@ SIGNATURES = {
     "incagg_device_count": (_int, []),
     "incagg_check_device_errors": (_int, []),
     "incagg_spmm_csr_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64,
-                                   _int, _f32, _vp, _i64, _f32, _i64, _i64, _vp, _vp, _i64, _vp]),
+                                   _int, _f32, _vp, _i64, _f32, _i64, _vp, _vp, _i64, _vp]),
     "incagg_spmm_csr_incagg_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
-                                          _i64, _int, _f32, _vp, _i64, _f32, _i64, _i64, _vp, _vp,
+                                          _i64, _int, _f32, _vp, _i64, _f32, _i64, _vp, _vp,
                                           _i64, _vp]),
+    "incagg_spmm_plan_defaults": (_int, [_vp, _vp]),
+    "incagg_spmm_plan_items_bound": (_i64, [_i64, _i64, _i32, _i32]),
+    "incagg_spmm_plan_host": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "incagg_spmm_plan_device_scratch_bytes": (_i64, [_i64]),
+    "incagg_spmm_plan_device": (_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp,
+                                       _i64, _vp, _vp]),
     "incagg_set_tuning": (_int, [_c.c_char_p, _int]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
@@ -53,6 +59,14 @@ SIGNATURES = {
 }
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1}
+ABI_VERSION = 2
+
+
+class SpmmPlanStruct(_c.Structure):
+    """``incagg_spmm_plan`` of include/incagg_gnn.h."""
+    _fields_ = [("order", _vp), ("items", _vp), ("multi_rows", _vp), ("n_rows", _i64),
+                ("n_hub", _i64), ("n_items", _i64), ("n_multi", _i64), ("hub_threshold", _i32),
+                ("segment_edges", _i32)]
 
 _handle = None
 
@@ -79,7 +93,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError here means header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if h.incagg_abi_version() != 1:
+        if h.incagg_abi_version() != ABI_VERSION:
             raise IncAggLibraryError("libincagg_gnn.so ABI version mismatch")
         _handle = h
     return _handle

@@ -37,7 +37,7 @@ class _SpMM(torch.autograd.Function):
             col = adj.col_in_place(halo_ids, x.size(0))
             n_cols = x.size(0) + x_halo.size(0)
         y = ops.spmm_csr(rowptr, col, val, x, n_cols, reduce, scale, add, add_scale,
-                         adj.max_row_nnz(), x_halo=x_halo, row_order=adj.row_order())
+                         x_halo=x_halo, plan=adj.plan())
         ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
         ctx.x_rows = x.size(0)
         ctx.halo_rows = None if x_halo is None else x_halo.size(0)
@@ -75,7 +75,7 @@ class _IncAgg(torch.autograd.Function):
     def forward(ctx, x, add, m_in, m_ag, adj, reduce, scale, add_scale):
         rowptr, col, val = adj.device_csr()
         h = ops.spmm_csr_incagg(rowptr, col, val, x, m_in, m_ag, reduce, scale, add, add_scale,
-                                adj.max_row_nnz(), row_order=adj.row_order())
+                                plan=adj.plan())
         ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
         ctx.x_rows = x.size(0)
         ctx.has_add = add is not None
@@ -97,11 +97,11 @@ def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: flo
                           hi: int, out_rows: int) -> Tensor:
     """Rows [lo, hi) of  scale * A^T dY  (A^T has one row per source row of A), padded
     with zero rows up to ``out_rows``."""
-    t_rowptr, t_col, t_val, t_max = adj.device_csr_t(reduce)
+    t_rowptr, t_col, t_val = adj.device_csr_t(reduce)
     hi = min(hi, adj.size(1))
     # a window of row pointers addresses the same col / val arrays: no copy
-    dx = ops.spmm_csr(t_rowptr[lo:hi + 1], t_col, t_val, dy, adj.size(0), "sum", scale, None,
-                      0.0, t_max, row_order=adj.row_order_t(reduce, lo, hi))
+    dx = ops.spmm_csr(t_rowptr[lo:hi + 1], t_col, t_val, dy, adj.size(0), "sum", scale,
+                      plan=adj.plan_t(reduce, lo, hi))
     if out_rows > hi - lo:  # x had rows the adjacency never references
         pad = torch.zeros((out_rows - (hi - lo), dy.size(1)), dtype=dy.dtype, device=dy.device)
         dx = torch.cat([dx, pad], dim=0)

@@ -48,14 +48,100 @@ def _need_cuda(t: Tensor, name: str) -> None:
 
 
 # --------------------------------------------------------------------------- aggregation
+class SpmmPlan:
+    """Work plan of one row-pointer array (``incagg_spmm_plan``): the rows by descending
+    length and the (row, segment) items of the long ones.  A pure function of the row pointers,
+    built once per adjacency at batch construction -- on the host for host-built batches
+    (then uploaded), on the GPU for device-built ones -- and passed to every aggregation call
+    over those row pointers.  The arrays are never replaced once built: recorded HIP graphs
+    hold their addresses."""
+
+    def __init__(self, order: Tensor, items: Tensor, multi_rows: Tensor, n_hub: int,
+                 n_items: int, n_multi: int, hub_threshold: int, segment_edges: int):
+        self.order, self.items, self.multi_rows = order, items, multi_rows
+        self.n_rows = int(order.numel())
+        self.n_hub, self.n_items, self.n_multi = int(n_hub), int(n_items), int(n_multi)
+        self.hub_threshold, self.segment_edges = int(hub_threshold), int(segment_edges)
+        self._struct = None
+
+    @property
+    def device(self):
+        return self.order.device
+
+    def to(self, device, non_blocking: bool = False) -> "SpmmPlan":
+        device = torch.device(device)
+        if device == self.order.device:
+            return self
+        return SpmmPlan(self.order.to(device, non_blocking=non_blocking),
+                        self.items.to(device, non_blocking=non_blocking),
+                        self.multi_rows.to(device, non_blocking=non_blocking), self.n_hub,
+                        self.n_items, self.n_multi, self.hub_threshold, self.segment_edges)
+
+    def struct(self) -> "_lib.SpmmPlanStruct":
+        if self._struct is None:
+            self._struct = _lib.SpmmPlanStruct(
+                _ptr(self.order), _ptr(self.items), _ptr(self.multi_rows), self.n_rows,
+                self.n_hub, self.n_items, self.n_multi, self.hub_threshold, self.segment_edges)
+        return self._struct
+
+    @staticmethod
+    def build(rowptr32: Tensor, nnz: Optional[int] = None, hub_threshold: int = 0,
+              segment_edges: int = 0) -> "SpmmPlan":
+        """Plan of ``rowptr32`` (int32; host or device, also a window of a longer array).
+        ``nnz``: an upper bound on the edges the rows address (sizes the item list without
+        reading device memory); default: read from the row pointers."""
+        if rowptr32.dtype != torch.int32 or rowptr32.dim() != 1 or rowptr32.numel() < 1:
+            raise TypeError("rowptr must be a 1-D int32 tensor with n_rows + 1 entries")
+        rowptr32 = rowptr32.contiguous()
+        n_rows = rowptr32.numel() - 1
+        if nnz is None:
+            nnz = int(rowptr32[-1] - rowptr32[0]) if n_rows else 0
+        L = lib()
+        cap = L.incagg_spmm_plan_items_bound(n_rows, int(nnz), hub_threshold, segment_edges)
+        check(cap)
+        dev = rowptr32.device
+        order = torch.empty(n_rows, dtype=torch.int32, device=dev)
+        items = torch.empty((max(cap, 1), 2), dtype=torch.int32, device=dev)
+        multi = torch.empty(max(min(n_rows, cap), 1), dtype=torch.int32, device=dev)
+        counts = (ctypes.c_int64 * 5)()
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                need = L.incagg_spmm_plan_device_scratch_bytes(n_rows)
+                check(need)
+                _, _, scratch = _build_workspace(dev, 0, need)
+                check(L.incagg_spmm_plan_device(
+                    rowptr32.data_ptr(), n_rows, hub_threshold, segment_edges,
+                    scratch.data_ptr(), scratch.numel(), _ptr(order), items.data_ptr(), cap,
+                    multi.data_ptr(), multi.numel(), ctypes.addressof(counts), _stream_of(dev)))
+        else:
+            check(L.incagg_spmm_plan_host(
+                rowptr32.data_ptr(), n_rows, hub_threshold, segment_edges, _ptr(order),
+                items.data_ptr(), cap, multi.data_ptr(), multi.numel(),
+                ctypes.addressof(counts)))
+        n_hub, n_items, n_multi, thr, seg = (int(c) for c in counts)
+        # keep only what is used (one copy at batch construction, never again)
+        return SpmmPlan(order, items[:max(n_items, 1)].clone(), multi[:max(n_multi, 1)].clone(),
+                        n_hub, n_items, n_multi, thr, seg)
+
+
+def _plan_ref(plan: Optional[SpmmPlan], n_rows: int, dev):
+    if plan is None:
+        return None
+    if plan.n_rows != n_rows:
+        raise ValueError(f"the plan was built for {plan.n_rows} rows, the call has {n_rows}")
+    if plan.device != dev:
+        raise ValueError(f"the plan is on {plan.device}, the call runs on {dev}")
+    return ctypes.addressof(plan.struct())
+
+
 def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, n_cols: int,
              reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
-             add_scale: float = 0.0, max_row_nnz: int = -1, out: Optional[Tensor] = None,
-             x_halo: Optional[Tensor] = None, row_order: Optional[Tensor] = None) -> Tensor:
+             add_scale: float = 0.0, out: Optional[Tensor] = None,
+             x_halo: Optional[Tensor] = None, plan: Optional[SpmmPlan] = None) -> Tensor:
     """y = scale * reduce_rows(A, [x ; x_halo]) + add_scale * add   (incagg_spmm_csr_f32).
 
     With ``x_halo`` the source rows ``[x.size(0), n_cols)`` are read from ``x_halo`` -- the
-    concatenation is never materialised."""
+    concatenation is never materialised.  ``plan``: :class:`SpmmPlan` of ``rowptr32``."""
     _need_cuda(x, "x")
     dev = x.device
     _rows_f32(x, "x")
@@ -64,8 +150,11 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
         raise TypeError("device CSR must be int32")
     if rowptr32.device != dev or col32.device != dev or (val is not None and val.device != dev):
         raise ValueError("CSR and x must be on the same device")
-    if val is not None and (val.dtype != torch.float32 or val.numel() != col32.numel()):
-        raise ValueError("val must be float32 with one entry per edge")
+    if not (rowptr32.is_contiguous() and col32.is_contiguous()):
+        raise ValueError("device CSR arrays must be contiguous")
+    if val is not None and (val.dtype != torch.float32 or val.numel() != col32.numel()
+                            or not val.is_contiguous()):
+        raise ValueError("val must be contiguous float32 with one entry per edge")
     width = x.size(1)
     n_split = n_cols
     if x_halo is not None:
@@ -93,40 +182,15 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(x_halo),
             0 if x_halo is None else _ld(x_halo), n_split, n_rows, n_cols, width,
             REDUCE[reduce], float(scale), _ptr(add), 0 if add is None else _ld(add),
-            float(add_scale), _window_nnz(rowptr32, col32), int(max_row_nnz),
-            _row_order_ptr(row_order, n_rows, dev), _ptr(out), _ld(out), _stream_of(dev)))
+            float(add_scale), int(col32.numel()), _plan_ref(plan, n_rows, dev), _ptr(out),
+            _ld(out), _stream_of(dev)))
     return out
-
-
-def _row_order_ptr(row_order: Optional[Tensor], n_rows: int, dev):
-    if row_order is None:
-        return None
-    if row_order.dtype != torch.int32 or row_order.device != dev or row_order.numel() != n_rows \
-            or not row_order.is_contiguous():
-        raise ValueError("row_order must be a contiguous int32 device vector with one entry per row")
-    return _ptr(row_order)
-
-
-def degree_order(rowptr32: Tensor) -> Tensor:
-    """Rows by descending length (stable): the ``row_order`` argument of the aggregation."""
-    deg = rowptr32[1:] - rowptr32[:-1]
-    return torch.argsort(deg, descending=True, stable=True).to(torch.int32)
-
-
-def _window_nnz(rowptr32: Tensor, col32: Tensor) -> int:
-    """Edge count of the rows addressed by ``rowptr32`` without reading device memory: the
-    full edge array, scaled by the share of rows when ``rowptr32`` is a window of a longer
-    row-pointer array (the transposed CSR restricted to in-batch columns)."""
-    base = rowptr32._base
-    if base is None or base.numel() <= 1:
-        return int(col32.numel())
-    return int(col32.numel() * (rowptr32.numel() - 1) / (base.numel() - 1))
 
 
 def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor,
                     m_in: Tensor, m_ag: Tensor, reduce: str = "sum", scale: float = 1.0,
-                    add: Optional[Tensor] = None, add_scale: float = 0.0, max_row_nnz: int = -1,
-                    out: Optional[Tensor] = None, row_order: Optional[Tensor] = None) -> Tensor:
+                    add: Optional[Tensor] = None, add_scale: float = 0.0,
+                    out: Optional[Tensor] = None, plan: Optional[SpmmPlan] = None) -> Tensor:
     """h = scale * (reduce_rows(A, x - m_in) + m_ag) + add_scale * add."""
     _need_cuda(x, "x")
     dev = x.device
@@ -138,6 +202,8 @@ def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: T
             raise ValueError(f"{name} must be at least [{n_rows}, {width}], got {tuple(t.shape)}")
     if rowptr32.dtype != torch.int32 or col32.dtype != torch.int32:
         raise TypeError("device CSR must be int32")
+    if not (rowptr32.is_contiguous() and col32.is_contiguous()):
+        raise ValueError("device CSR arrays must be contiguous")
     if add is not None:
         _rows_f32(add, "add", dev)
         if add.size(0) < n_rows or add.size(1) != width:
@@ -149,8 +215,7 @@ def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: T
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(m_in), _ld(m_in),
             _ptr(m_ag), _ld(m_ag), n_rows, width, REDUCE[reduce], float(scale), _ptr(add),
             0 if add is None else _ld(add), float(add_scale), int(col32.numel()),
-            int(max_row_nnz), _row_order_ptr(row_order, n_rows, dev), _ptr(out), _ld(out),
-            _stream_of(dev)))
+            _plan_ref(plan, n_rows, dev), _ptr(out), _ld(out), _stream_of(dev)))
     return out
 
 

@@ -78,7 +78,7 @@ class SparseTensor:
         self._value = value
         self._row: Optional[Tensor] = None
         self._host: Optional["SparseTensor"] = None   # CPU original of a GPU copy
-        self._transposed = {}                         # reduce -> (rowptr32, col32, val, max_nnz)
+        self._transposed = {}                         # reduce -> (rowptr32, col32, val)
         self._max_row_nnz: Optional[int] = None
         self.storage = _Storage(self)
 
@@ -200,7 +200,9 @@ class SparseTensor:
             out._host = self if self._device.type == "cpu" else self._host
             out._transposed = {}
             out._max_row_nnz = self.max_row_nnz()
-            out._orders = {"rows": ops.degree_order(self._rowptr32()).to(
+            # the aggregation's work plan is part of batch construction: built on the host
+            # from the row pointers, uploaded with them
+            out._plans = {"rows": ops.SpmmPlan.build(self._rowptr32(), self.nnz()).to(
                 out._device, non_blocking=non_blocking)}
             out.storage = _Storage(out)
             if hasattr(self, "_halo_plan"):
@@ -224,7 +226,7 @@ class SparseTensor:
     # everything derived from the STRUCTURE alone.  Everything that holds values (transposed
     # CSR, uploaded copies, the in-batch view, the value-less view) is rebuilt on demand.
     _STRUCTURE_KEYS = ("_sizes", "_device", "_rowptr_i64", "_col_i64", "_rowptr_i32", "_col_i32",
-                       "_row", "_max_row_nnz", "_orders", "_in_place_cols", "_halo_plan",
+                       "_row", "_max_row_nnz", "_plans", "_in_place_cols", "_halo_plan",
                        "_ids_on_device")
 
     def set_value(self, value: Optional[Tensor], layout: Optional[str] = None) -> "SparseTensor":
@@ -343,53 +345,48 @@ class SparseTensor:
         cache[key] = (out, stamp, halo_ids)
         return out
 
-    def row_order(self) -> Tensor:
-        """Rows by descending length, on the device.  Built on the host when the adjacency is
-        uploaded (part of batch construction), else on first use."""
-        cache = self.__dict__.setdefault("_orders", {})
+    def plan(self) -> "ops.SpmmPlan":
+        """Work plan of the aggregation over this adjacency (rows by descending length, long
+        rows cut into workgroup items), on the device.  Built on the host when the adjacency
+        is uploaded (part of batch construction), else on first use, on the device."""
+        cache = self.__dict__.setdefault("_plans", {})
         if "rows" not in cache:
-            cache["rows"] = ops.degree_order(self._rowptr32())
+            cache["rows"] = ops.SpmmPlan.build(self._rowptr32(), self.nnz())
         return cache["rows"]
 
-    def row_order_t(self, reduce: str, lo: int, hi: int) -> Tensor:
+    def plan_t(self, reduce: str, lo: int, hi: int) -> "ops.SpmmPlan":
         """The same for rows [lo, hi) of the transposed CSR (device_csr_t prepares the two
         windows the backward pass uses: all columns, and the in-batch columns)."""
-        cache = self.__dict__.setdefault("_orders", {})
+        cache = self.__dict__.setdefault("_plans", {})
         key = ("t", lo, hi)
         if key not in cache:
-            cache[key] = ops.degree_order(self.device_csr_t(reduce)[0][lo:hi + 1])
+            cache[key] = ops.SpmmPlan.build(self.device_csr_t(reduce)[0][lo:hi + 1], self.nnz())
         return cache[key]
 
     def device_csr_t(self, reduce: str = "sum"):
         """Transposed CSR for dX = A^T dY, with 1/len(row) folded in for 'mean'."""
         key = "mean" if reduce == "mean" else "sum"
         if key not in self._transposed:
+            n_r, n_c = self._sizes
+            windows = {(0, n_c), (0, min(n_r, n_c))}
+            plans = self.__dict__.setdefault("_plans", {})
             if self._host is None and self._device.type == "cuda":
                 # built on the device: transposed there too (same element order)
                 t_rowptr, t_col, t_val = ops.csr_transpose_device(
-                    self._rowptr32(), self._col32(), self._value, self._sizes[0], self._sizes[1],
-                    key)
-                cnt = t_rowptr[1:] - t_rowptr[:-1]
-                max_nnz = int(cnt.max()) if cnt.numel() else 0
-                self._transposed[key] = (t_rowptr, t_col, t_val, max_nnz)
-                orders = self.__dict__.setdefault("_orders", {})
-                n_r, n_c = self._sizes
-                for lo, hi in {(0, n_c), (0, min(n_r, n_c))}:
-                    orders[("t", lo, hi)] = ops.degree_order(t_rowptr[lo:hi + 1])
+                    self._rowptr32(), self._col32(), self._value, n_r, n_c, key)
+                self._transposed[key] = (t_rowptr, t_col, t_val)
+                for lo, hi in windows:
+                    plans[("t", lo, hi)] = ops.SpmmPlan.build(t_rowptr[lo:hi + 1], self.nnz())
                 return self._transposed[key]
             src = self._host if self._host is not None else self
             rowptr, col, value = src.csr()
-            t_rowptr, t_col, t_val = ops.csr_transpose(rowptr, col, value, self._sizes[0],
-                                                       self._sizes[1], key)
-            cnt = t_rowptr[1:] - t_rowptr[:-1]
-            max_nnz = int(cnt.max()) if cnt.numel() else 0
+            t_rowptr, t_col, t_val = ops.csr_transpose(rowptr, col, value, n_r, n_c, key)
             dev = self._device
-            self._transposed[key] = (t_rowptr.to(dev), t_col.to(dev), t_val.to(dev), max_nnz)
+            self._transposed[key] = (t_rowptr.to(dev), t_col.to(dev), t_val.to(dev))
             if dev.type == "cuda":
-                orders = self.__dict__.setdefault("_orders", {})
-                n_r, n_c = self._sizes
-                for lo, hi in {(0, n_c), (0, min(n_r, n_c))}:
-                    orders[("t", lo, hi)] = ops.degree_order(t_rowptr[lo:hi + 1]).to(dev)
+                for lo, hi in windows:
+                    plans[("t", lo, hi)] = ops.SpmmPlan.build(t_rowptr[lo:hi + 1],
+                                                              self.nnz()).to(dev)
         return self._transposed[key]
 
     # ------------------------------------------------------------------ aggregation

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INCAGG_ABI_VERSION 1
+#define INCAGG_ABI_VERSION 2
 
 enum {
   INCAGG_OK = 0,
@@ -72,37 +72,42 @@ int incagg_check_device_errors(void);
  *     "fresh in-batch rows + pulled out-of-batch History rows" without materialising
  *     their concatenation (the torch.cat of models/base.py:426,451).
  *   reduce: INCAGG_REDUCE_SUM | INCAGG_REDUCE_MEAN (divide by max(row length, 1))
- *   nnz: number of edges (= rowptr[n_rows] - rowptr[0]; the host cannot read it from the
- *     device array), used to pick the kernel variant by average row length.
- *   max_row_nnz: length of the longest row if the caller knows it, else -1.
- *   row_order (may be NULL): device int32[n_rows], a permutation of the rows in which rows
- *     of similar length are neighbours; only the processing order changes (the variant that
- *     runs 8 rows per wave uses it to balance its lane groups), never the result layout.
- *   y[n_rows, width] ld = ldy; must not alias x.
+ *   nnz: number of entries of col / val.  A window of a longer row-pointer array may be
+ *     passed as `rowptr` (the transposed CSR restricted to some rows): its values then do not
+ *     start at 0 and nnz is still the length of the whole col array.  Row pointers outside
+ *     [0, nnz] are skipped and reported (incagg_check_device_errors), never followed.
+ *   plan (may be NULL): the work plan of this rowptr, see incagg_spmm_plan below.  Without a
+ *     plan the rows are processed in storage order and every row by one wave (or one group of 8
+ *     lanes), however long it is: correct, but slow on power-law graphs.
+ *   y[n_rows, width] ld = ldy; must not alias x, x_halo or add.
  *   width <= 1024 when every pointer is 16-byte aligned and every ld a multiple
  *   of 4, else width <= 256.
  *
- * Three kernel variants, chosen by shape: whole rows per wave; 128-byte feature slices
- * pinned to one XCD each so that every source byte has a single home L2, one row per wave
- * (width >= 64, one source matrix, >= 16 edges per row on average); and the same slices
- * with 8 rows per wave (whenever row_order is given and the rows are 16-byte aligned).
- * Rows longer than 128 (256 in the second variant) edges are cut into 64 (128)-edge slices
- * that are summed onto the row with fp32 atomics by a second launch (skipped when
- * max_row_nnz says there is no such row), so such rows are reproducible only up to fp32
- * rounding order.  The slice queue is device memory the library allocates once per
- * (device, stream) on the first call that may need it.
- * HIP graphs: a call may be recorded into a stream capture once the queue of that stream exists
- * (run one aggregation on the stream before capturing it; allocation is impossible during
- * capture and the call fails with a message saying so).  A recorded call keeps using the
- * queue of the stream it was recorded on, wherever the graph is replayed: replays of such
- * graphs, and eager aggregations on the recording stream, must not overlap in time.
+ * One launch per call (two when the plan holds rows cut into several segments: those rows are
+ * zeroed first and their segments combined with fp32 atomics; every other row is written by
+ * exactly one wave with a fixed summation order, i.e. bit-reproducibly).  Two kernels, chosen
+ * by alignment: 128-byte feature slices pinned to one XCD each so that every source byte has a
+ * single home L2, 8 short rows per wave; or whole rows per wave (any width / alignment).  The
+ * call allocates nothing, keeps no state between calls and may be recorded into a HIP graph.
  */
+typedef struct incagg_spmm_plan {
+  const int32_t *order;      /* device int32[n_rows]: rows by descending length, ties by row id */
+  const int32_t *items;      /* device int32[2 * n_items]: (row, segment) of the long rows */
+  const int32_t *multi_rows; /* device int32[n_multi]: rows with more than one segment */
+  int64_t n_rows;
+  int64_t n_hub;             /* rows longer than hub_threshold = the first n_hub of `order` */
+  int64_t n_items;
+  int64_t n_multi;
+  int32_t hub_threshold;
+  int32_t segment_edges;     /* edges per item, a multiple of 64 */
+} incagg_spmm_plan;
+
 int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                         const float *x, int64_t ldx, const float *x_halo, int64_t ld_halo,
                         int64_t n_split, int64_t n_rows, int64_t n_cols, int64_t width,
                         int reduce, float scale, const float *add, int64_t ldadd,
-                        float add_scale, int64_t nnz, int64_t max_row_nnz,
-                        const int32_t *row_order, float *y, int64_t ldy, void *stream);
+                        float add_scale, int64_t nnz, const incagg_spmm_plan *plan, float *y,
+                        int64_t ldy, void *stream);
 
 /*
  * Fused incremental aggregate (the fork's contribution):
@@ -118,16 +123,45 @@ int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col, const 
                                int64_t ldin, const float *m_ag, int64_t ldag,
                                int64_t n_rows, int64_t width, int reduce, float scale,
                                const float *add, int64_t ldadd, float add_scale, int64_t nnz,
-                               int64_t max_row_nnz, const int32_t *row_order, float *h,
-                               int64_t ldh, void *stream);
+                               const incagg_spmm_plan *plan, float *h, int64_t ldh,
+                               void *stream);
+
+/*
+ * Work plan of an aggregation: a pure function of the row pointers, built once per batch next
+ * to the relabelling (it replaces the per-step mask / sort work of models/gcn.py:117-135 and
+ * has no other counterpart in the reference, whose SpMM kernels live in torch-sparse).
+ *   order[n_rows]        rows by descending length (stable: ties in ascending row id)
+ *   items[2 * n_items]   for the n_hub rows longer than hub_threshold, in that order, one
+ *                        (row, segment) pair per started segment of segment_edges edges
+ *   multi_rows[n_multi]  the rows with more than one segment
+ * hub_threshold / segment_edges <= 0 select the library defaults (incagg_spmm_plan_defaults).
+ * Capacities: incagg_spmm_plan_items_bound(n_rows, nnz, ...) entries suffice for `items`,
+ * min(n_rows, nnz / segment_edges) for `multi_rows`.
+ * counts (HOST int64[5]): n_hub, n_items, n_multi, hub_threshold used, segment_edges used.
+ * incagg_spmm_plan_host:   rowptr and all outputs are host arrays (upload them afterwards).
+ * incagg_spmm_plan_device: rowptr and all outputs are device arrays; scratch >=
+ *   incagg_spmm_plan_device_scratch_bytes(n_rows); enqueues on `stream`, then waits for it (the
+ *   counts come back).  Both produce identical arrays.
+ */
+int incagg_spmm_plan_defaults(int32_t *hub_threshold, int32_t *segment_edges);
+int64_t incagg_spmm_plan_items_bound(int64_t n_rows, int64_t nnz, int32_t hub_threshold,
+                                     int32_t segment_edges);
+int incagg_spmm_plan_host(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
+                          int32_t segment_edges, int32_t *order, int32_t *items,
+                          int64_t items_cap, int32_t *multi_rows, int64_t multi_cap,
+                          int64_t *counts);
+int64_t incagg_spmm_plan_device_scratch_bytes(int64_t n_rows);
+int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
+                            int32_t segment_edges, void *scratch, int64_t scratch_bytes,
+                            int32_t *order, int32_t *items, int64_t items_cap,
+                            int32_t *multi_rows, int64_t multi_cap, int64_t *counts,
+                            void *stream);
 
 /*
  * Launch tuning of the aggregation (no counterpart in the reference; for benchmarks and
- * tests).  Keys: "spmm_sliced" (-1 choose by shape, 0 whole rows per wave, 1 feature slices
- * with one row per wave, 2 feature slices with 8 rows per wave), "hub_threshold", "hub_slice",
- * "hub_blocks", "sliced_hub_threshold", "sliced_hub_slice", "sliced_rows_per_wave",
- * "grouped_hub_threshold", "grouped_hub_slice".  Not thread-safe against concurrent
- * aggregation calls.
+ * tests).  Keys: "spmm_variant" (-1 feature slices whenever the rows are 16-byte aligned, 0
+ * always whole rows per wave, 1 as -1), "hub_threshold", "segment_edges" (defaults of the plan
+ * builders).  Not thread-safe against concurrent aggregation calls.
  */
 int incagg_set_tuning(const char *key, int value);
 

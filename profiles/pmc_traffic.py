@@ -4,15 +4,22 @@
 KiB-sized units of 1024 B as rocprofv3 reports them for gfx950; FETCH_SIZE counts 128-byte
 requests at 64 B and is doubled (checked against a pure row gather of known size, see
 r01_pmc_notes.txt), WRITE_SIZE is exact.  A "launch" is one call of the aggregation entry
-point: the main kernel plus, when rows were cut into slices, the slice kernel.
+point: the aggregation kernel plus, when the plan holds rows cut into several segments, the
+small launch that zeroes those rows first.  The output names the SHA-256 of the kernel source
+it was measured with; bench.py reports the figure only while that still matches.
 Usage: pmc_traffic.py <fetch_dir> <write_dir> <steps> <launches_per_step> > traffic.json"""
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 
-MAIN = ("spmm_rows_kernel", "spmm_sliced_kernel", "spmm_grouped_kernel")
-SECOND = ("spmm_hub_kernel", "spmm_sliced_hub_kernel")
+KERNEL_SOURCE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                             "incagg-gnn_amd", "csrc", "aggregate.hip")
+
+MAIN = ("spmm_rows_kernel", "spmm_plan_kernel")
+SECOND = ("zero_rows_kernel",)
 
 
 def per_launch(d, counter, steps, per_step):
@@ -37,6 +44,7 @@ def main():
         "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
         "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is",
         "traffic_bytes_per_launch": (2 * fetch + write) * 1024,
+        "kernel_source_sha256": hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest(),
     }, indent=1))
 
 

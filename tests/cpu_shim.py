@@ -15,16 +15,30 @@ def _np(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
-def _check_order(row_order, n_rows):
-    # the processing order must be a permutation of the rows the call addresses
-    if row_order is not None:
-        assert row_order.dtype == torch.int32 and row_order.numel() == n_rows
-        assert torch.equal(torch.sort(row_order.to(torch.int64)).values, torch.arange(n_rows))
+def _check_plan(plan, rowptr32):
+    """The plan must describe the rows the call addresses: a permutation by descending length
+    whose long prefix is covered segment by segment."""
+    if plan is None:
+        return
+    n_rows = rowptr32.numel() - 1
+    assert plan.n_rows == n_rows and plan.order.dtype == torch.int32
+    order = plan.order.to(torch.int64).cpu()
+    assert torch.equal(torch.sort(order).values, torch.arange(n_rows))
+    deg = (rowptr32[1:] - rowptr32[:-1]).to(torch.int64).cpu()
+    d = deg[order]
+    assert torch.all(d[:-1] >= d[1:]) if n_rows > 1 else True
+    assert plan.n_hub == int((deg > plan.hub_threshold).sum())
+    want = [(int(r), s) for r in order[:plan.n_hub].tolist()
+            for s in range(-(-int(deg[r]) // plan.segment_edges))]
+    got = [tuple(p) for p in plan.items[:plan.n_items].cpu().tolist()]
+    assert got == want
+    multi = [int(r) for r in order[:plan.n_hub].tolist() if int(deg[r]) > plan.segment_edges]
+    assert plan.multi_rows[:plan.n_multi].cpu().tolist() == multi
 
 
 def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None, add_scale=0.0,
-              max_row_nnz=-1, out=None, x_halo=None, row_order=None):
-    _check_order(row_order, rowptr32.numel() - 1)
+              out=None, x_halo=None, plan=None):
+    _check_plan(plan, rowptr32)
     if x_halo is not None:
         x = torch.cat([x, x_halo], dim=0)
     y = cp.spmm(_np(rowptr32).astype(np.int64), _np(col32).astype(np.int64), _np(val),
@@ -39,8 +53,8 @@ def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None
 
 
 def _spmm_csr_incagg(rowptr32, col32, val, x, m_in, m_ag, reduce="sum", scale=1.0, add=None,
-                     add_scale=0.0, max_row_nnz=-1, out=None, row_order=None):
-    _check_order(row_order, rowptr32.numel() - 1)
+                     add_scale=0.0, out=None, plan=None):
+    _check_plan(plan, rowptr32)
     b, w = rowptr32.numel() - 1, x.size(1)
     h = cp.incagg(_np(rowptr32).astype(np.int64), _np(col32).astype(np.int64), _np(val),
                   _np(x[:b]), _np(m_in[:b, :w]), _np(m_ag[:b, :w]), reduce)

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_reports_version_and_device_count():
     from torch_geometric_autoscale import _lib
-    assert _lib.lib().incagg_abi_version() == 1
+    assert _lib.lib().incagg_abi_version() == _lib.ABI_VERSION
     assert _lib.device_count() >= 0
     assert _lib.last_error() is not None
 

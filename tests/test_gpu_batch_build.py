@@ -190,7 +190,11 @@ def test_device_partition_batch_drives_the_model_like_the_host_batch(ops, dev):
         for a, b in zip(devb.data.adj_t.device_csr_t("sum")[:3], h_adj.device_csr_t("sum")[:3]):
             assert torch.equal(a, b)
         assert devb.data.adj_t.max_row_nnz() == h_adj.max_row_nnz()
-        assert torch.equal(devb.data.adj_t.row_order(), h_adj.row_order())
+        # the aggregation's work plan: built on the device for one, on the host for the other
+        pd, ph = devb.data.adj_t.plan(), h_adj.plan()
+        assert (pd.n_hub, pd.n_items, pd.n_multi) == (ph.n_hub, ph.n_items, ph.n_multi)
+        assert torch.equal(pd.order, ph.order)
+        assert torch.equal(pd.items[:pd.n_items], ph.items[:ph.n_items])
 
     torch.manual_seed(0)
     model = GCN2(20000, 24, 32, 5, 3, alpha=0.1, theta=0.5, shared_weights=False, dropout=0.0,
