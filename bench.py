@@ -360,14 +360,21 @@ def main():
     if graphs is not None:
         # The timed steps were graph replays, into which no timing events can be placed: the
         # per-launch durations come from an eager pass over the same K steps, right away.
+        # The events must bracket device time only: the stream is first given ~0.25 s of spin
+        # work, so that the host enqueues the whole pass ahead of the GPU and every start event
+        # is reached the moment the preceding kernel ends (an eager step takes the host longer
+        # to issue than the GPU to run; without the head start the intervals would include the
+        # host's time between recording the event and launching the kernel).
         clock.enabled = True
+        torch.cuda._sleep(int(0.25 * 2.0e9))
         for i in range(args.steps):
             eager_step((args.warmup + i) % len(batches))
         torch.cuda.synchronize()
         clock.enabled = False
         kernel_timing = ("HIP events around every aggregation launch in an eager pass over the "
-                         "same K steps run right after the timed region (the timed steps are HIP "
-                         "graph replays, which cannot carry timing events)")
+                         "same K steps run right after the timed region, enqueued behind 0.25 s "
+                         "of spin work so that the intervals hold device time only (the timed "
+                         "steps are HIP graph replays, which cannot carry timing events)")
     if os.environ.get("BENCH_TRACE"):   # host-side enqueue time of every step
         print("enqueue ms/step:", " ".join(f"{(b - a) * 1e3:.2f}" for a, b in
                                              zip(host_marks, host_marks[1:])), file=sys.stderr)
