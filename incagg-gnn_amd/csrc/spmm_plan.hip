@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -176,27 +177,12 @@ extern "C" int64_t incagg_spmm_plan_device_scratch_bytes(int64_t n_rows) {
                    up256(std::max(sort, scan)));
 }
 
-extern "C" int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
-                                       int32_t segment_edges, void *scratch, int64_t scratch_bytes,
-                                       int32_t *order, int32_t *items, int64_t items_cap,
-                                       int32_t *multi_rows, int64_t multi_cap, int64_t *counts,
-                                       void *stream_) {
-  INCAGG_REQUIRE(counts != nullptr, "null counts");
-  INCAGG_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 64, "row count out of range");
-  int rc = resolve(hub_threshold, segment_edges);
-  if (rc) return rc;
-  counts[0] = counts[1] = counts[2] = 0;
-  counts[3] = hub_threshold;
-  counts[4] = segment_edges;
-  if (n_rows == 0) return INCAGG_OK;
-  INCAGG_REQUIRE(rowptr && order, "null rowptr or order");
-  INCAGG_REQUIRE(items_cap >= 0 && multi_cap >= 0 && (items_cap == 0 || items) &&
-                     (multi_cap == 0 || multi_rows), "bad capacities");
-  const int64_t need = incagg_spmm_plan_device_scratch_bytes(n_rows);
-  INCAGG_REQUIRE(scratch && scratch_bytes >= need, "scratch too small: %lld < %lld",
-                 (long long)scratch_bytes, (long long)need);
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int n = (int)n_rows;
+// Enqueues the device builder; the counts stay in *status_out (device memory inside scratch).
+static int plan_device_enqueue(const int32_t *rowptr, int n, int32_t hub_threshold,
+                               int32_t segment_edges, void *scratch, int64_t scratch_bytes,
+                               int32_t *order, int32_t *items, int64_t items_cap,
+                               int32_t *multi_rows, int64_t multi_cap, PlanStatus **status_out,
+                               hipStream_t stream) {
   char *base = static_cast<char *>(scratch);
   const size_t e = up256(sizeof(int) * (size_t)n);
   PlanStatus *st = reinterpret_cast<PlanStatus *>(base);
@@ -230,6 +216,34 @@ extern "C" int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, in
                      multi_off, n, hub_threshold, (long long)items_cap, (long long)multi_cap,
                      reinterpret_cast<int2 *>(items), multi_rows, st);
   INCAGG_HIP_TRY(hipGetLastError());
+  *status_out = st;
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
+                                       int32_t segment_edges, void *scratch, int64_t scratch_bytes,
+                                       int32_t *order, int32_t *items, int64_t items_cap,
+                                       int32_t *multi_rows, int64_t multi_cap, int64_t *counts,
+                                       void *stream_) {
+  INCAGG_REQUIRE(counts != nullptr, "null counts");
+  INCAGG_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 64, "row count out of range");
+  int rc = resolve(hub_threshold, segment_edges);
+  if (rc) return rc;
+  counts[0] = counts[1] = counts[2] = 0;
+  counts[3] = hub_threshold;
+  counts[4] = segment_edges;
+  if (n_rows == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(rowptr && order, "null rowptr or order");
+  INCAGG_REQUIRE(items_cap >= 0 && multi_cap >= 0 && (items_cap == 0 || items) &&
+                     (multi_cap == 0 || multi_rows), "bad capacities");
+  const int64_t need = incagg_spmm_plan_device_scratch_bytes(n_rows);
+  INCAGG_REQUIRE(scratch && scratch_bytes >= need, "scratch too small: %lld < %lld",
+                 (long long)scratch_bytes, (long long)need);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PlanStatus *st = nullptr;
+  rc = plan_device_enqueue(rowptr, (int)n_rows, hub_threshold, segment_edges, scratch, scratch_bytes,
+                           order, items, items_cap, multi_rows, multi_cap, &st, stream);
+  if (rc) return rc;
   PlanStatus host{};
   INCAGG_HIP_TRY(hipMemcpyAsync(&host, st, sizeof(PlanStatus), hipMemcpyDeviceToHost, stream));
   INCAGG_HIP_TRY(hipStreamSynchronize(stream));
@@ -240,5 +254,88 @@ extern "C" int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, in
   counts[0] = host.n_hub;
   counts[1] = host.n_items;
   counts[2] = host.n_multi;
+  return INCAGG_OK;
+}
+
+// ---------------------------------------------------------------- the builder that allocates nothing
+// Same kernels, same outputs as incagg_spmm_plan_device, with the work arrays in a fixed array
+// of the code object instead of a caller-provided workspace, and the counts left on the device
+// (no host copy, no wait).  Every GPU holds its own copy of the array, at its own address,
+// until the process ends; calls on one GPU share it, so calls that overlap in time race.
+namespace incagg {
+
+constexpr int64_t kStaticPlanRows = 262144;
+constexpr size_t kStaticPlanBytes = 12u << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticPlanBytes];
+
+static constexpr int kMaxPlanDevices = 64;
+static unsigned char *s_scratch_ptr[kMaxPlanDevices] = {};
+static std::mutex s_scratch_mutex;
+
+// Device address of `scratch` on the current device (its name is only a host-side handle).
+static int static_scratch(unsigned char **out) {
+  int dev = 0;
+  INCAGG_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxPlanDevices) return fail(INCAGG_E_INVALID, "device id %d unsupported", dev);
+  std::lock_guard<std::mutex> lock(s_scratch_mutex);
+  if (!s_scratch_ptr[dev]) {
+    void *p = nullptr;
+    INCAGG_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    s_scratch_ptr[dev] = static_cast<unsigned char *>(p);
+  }
+  *out = s_scratch_ptr[dev];
+  return INCAGG_OK;
+}
+
+__global__ void plan_publish_kernel(const PlanStatus *st, int hub_threshold, int segment_edges,
+                                    int *counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    counts[0] = st->n_hub;
+    counts[1] = st->n_items;
+    counts[2] = st->n_multi;
+    counts[3] = hub_threshold;
+    counts[4] = segment_edges;
+    counts[5] = st->error;
+  }
+}
+
+}  // namespace incagg
+
+extern "C" int64_t incagg_spmm_plan_device_static_max_rows(void) { return kStaticPlanRows; }
+
+extern "C" int incagg_spmm_plan_device_static(const int32_t *rowptr, int64_t n_rows,
+                                              int32_t hub_threshold, int32_t segment_edges,
+                                              int32_t *order, int32_t *items, int64_t items_cap,
+                                              int32_t *multi_rows, int64_t multi_cap,
+                                              int32_t *counts_dev, void *stream_) {
+  INCAGG_REQUIRE(counts_dev != nullptr, "null counts");
+  INCAGG_REQUIRE(n_rows >= 1, "the static builder needs at least one row");
+  INCAGG_REQUIRE(n_rows <= kStaticPlanRows,
+                 "%lld rows exceed the %lld the fixed work array is sized for: use "
+                 "incagg_spmm_plan_device with a workspace", (long long)n_rows,
+                 (long long)kStaticPlanRows);
+  int rc = resolve(hub_threshold, segment_edges);
+  if (rc) return rc;
+  INCAGG_REQUIRE(rowptr && order, "null rowptr or order");
+  INCAGG_REQUIRE(items_cap >= 0 && multi_cap >= 0 && (items_cap == 0 || items) &&
+                     (multi_cap == 0 || multi_rows), "bad capacities");
+  const int64_t need = incagg_spmm_plan_device_scratch_bytes(n_rows);
+  INCAGG_REQUIRE(need >= 0 && (size_t)need <= kStaticPlanBytes,
+                 "work arrays for %lld rows need %lld bytes, the fixed array has %zu",
+                 (long long)n_rows, (long long)need, kStaticPlanBytes);
+  unsigned char *ws = nullptr;
+  rc = static_scratch(&ws);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PlanStatus *st = nullptr;
+  // (the status word and every work array are (re)written by the kernels below before they are
+  // read: nothing of an earlier call's contents is used)
+  rc = plan_device_enqueue(rowptr, (int)n_rows, hub_threshold, segment_edges, ws,
+                           (int64_t)kStaticPlanBytes, order, items, items_cap, multi_rows, multi_cap,
+                           &st, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(plan_publish_kernel, dim3(1), dim3(64), 0, stream, st, hub_threshold,
+                     segment_edges, counts_dev);
+  INCAGG_HIP_TRY(hipGetLastError());
   return INCAGG_OK;
 }

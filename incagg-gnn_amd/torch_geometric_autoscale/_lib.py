@@ -30,6 +30,9 @@ SIGNATURES = {
     "incagg_spmm_plan_device_scratch_bytes": (_i64, [_i64]),
     "incagg_spmm_plan_device": (_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp,
                                        _i64, _vp, _vp]),
+    "incagg_spmm_plan_device_static_max_rows": (_i64, []),
+    "incagg_spmm_plan_device_static": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64,
+                                              _vp, _vp]),
     "incagg_set_tuning": (_int, [_c.c_char_p, _int]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),

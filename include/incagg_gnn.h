@@ -158,6 +158,25 @@ int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, int32_t hub_t
                             void *stream);
 
 /*
+ * incagg_spmm_plan_device without any allocation, workspace argument, host copy or wait.  It
+ * has no counterpart in the reference; it is for callers that cannot allocate: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  The work arrays live
+ * in a fixed 12 MiB array of the library's code object (one copy per GPU, held until the
+ * process ends), which bounds the input: 1 <= n_rows <= incagg_spmm_plan_device_static_max_rows()
+ * (262,144); larger inputs are rejected with INCAGG_E_INVALID.  Outputs are those of
+ * incagg_spmm_plan_device, element for element; the counts stay on the device:
+ *   counts_dev (device int32[6]): n_hub, n_items, n_multi, hub_threshold used, segment_edges
+ *   used, error (0 ok, 1 row pointers decrease, 2 a capacity was exceeded).
+ * Only enqueues on `stream`.  All calls on one GPU share the fixed array: calls that overlap
+ * in time (different streams, replays of graphs holding such calls) race.
+ */
+int64_t incagg_spmm_plan_device_static_max_rows(void);
+int incagg_spmm_plan_device_static(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
+                                   int32_t segment_edges, int32_t *order, int32_t *items,
+                                   int64_t items_cap, int32_t *multi_rows, int64_t multi_cap,
+                                   int32_t *counts_dev, void *stream);
+
+/*
  * Launch tuning of the aggregation (no counterpart in the reference; for benchmarks and
  * tests).  Keys: "spmm_variant" (-1 feature slices whenever the rows are 16-byte aligned, 0
  * always whole rows per wave, 1 as -1), "hub_threshold", "segment_edges" (defaults of the plan
