@@ -32,6 +32,21 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal
+MODEL_NAMES = {"gcn2": "GCN2", "gcn": "GCN", "appnp": "APPNP", "sage": "GraphSAGE"}
+
+# BASELINE.json configs[1..4] as concrete synthetic workloads (sizes: the public statistics of
+# the named datasets; layer counts / partitions per batch from conf/model/*.yaml where
+# BASELINE.json leaves them open).
+PRESETS = {
+    "products-gcn2": dict(dataset="products", parts=150, batch_parts=1, model="gcn2", layers=8,
+                          hidden=256, tables="hbm", mode="gas"),
+    "arxiv-gcn": dict(dataset="arxiv", parts=80, batch_parts=40, model="gcn", layers=3, hidden=256,
+                      tables="hbm", mode="gas"),
+    "reddit-appnp": dict(dataset="reddit", parts=200, batch_parts=100, model="appnp", layers=5,
+                         hidden=256, tables="hbm", mode="gas"),
+    "products-sage-host": dict(dataset="products", parts=150, batch_parts=1, model="sage", layers=3,
+                               hidden=256, tables="host", mode="gas"),
+}
 
 
 def parse():
@@ -39,13 +54,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dataset", default="products")
-    ap.add_argument("--parts", type=int, default=150)
-    ap.add_argument("--layers", type=int, default=8)
-    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--config", default="products-gcn2", choices=sorted(PRESETS),
+                    help="BASELINE.json configuration (the headline one by default); the flags "
+                         "below override single values of it")
+    ap.add_argument("--dataset", default=None)
+    ap.add_argument("--parts", type=int, default=None)
+    ap.add_argument("--batch-parts", type=int, default=None, help="partitions per batch")
+    ap.add_argument("--model", default=None, choices=["gcn2", "gcn", "appnp", "sage"])
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--tables", default=None, choices=["hbm", "host"],
+                    help="History tables in HBM, or in pinned host memory behind the staging pools")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink nodes and edges together")
     ap.add_argument("--cross", type=float, default=0.15, help="fraction of inter-community edges")
-    ap.add_argument("--mode", default="gas", choices=["gas", "vr"],
+    ap.add_argument("--mode", default=None, choices=["gas", "vr"],
                     help="push/pull training step (headline) or incremental-aggregation step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", choices=["auto", "on", "off"], default="auto",
@@ -54,12 +76,17 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the partition-parallel code path even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--unfused-incagg", action="store_true",
-                    help="vr mode: x - M_in as a pass of its own, then the plain aggregation")
+    ap.add_argument("--fused-incagg", action="store_true",
+                    help="vr mode: A (x - M_in) + M_ag as one launch gathering both operands "
+                         "(default: x - M_in as a pass of its own, then the plain aggregation)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay every step from a HIP graph recorded once per batch "
                          "(auto: on for a single GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    for k, v in PRESETS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
 
 
 class KernelClock:
@@ -69,8 +96,11 @@ class KernelClock:
     def __init__(self):
         self.records = []   # (start, end, algorithmic_bytes, gather_bytes, edges)
         self.enabled = False
-        # distinct source rows of an edge array, where the call's n_cols is not that number
-        # (out-of-batch rows read in place from a whole History table): col data_ptr -> count
+        self.counting = False   # set-up pass: add up the edges every launch processes (reads
+        self.edges = 0          # the row pointers back, i.e. waits for the device)
+        # distinct source rows an edge array references (col data_ptr -> count), filled in the
+        # counting pass: the call's n_cols is not that number when out-of-batch rows are read in
+        # place from a whole History table
         self.sources = {}
 
     def wrap(self, ops):
@@ -78,6 +108,10 @@ class KernelClock:
         clock = self
 
         def timed(rowptr32, col32, val, x, n_cols, *a, **k):
+            if clock.counting and rowptr32.numel() > 1:
+                clock.edges += int(rowptr32[-1] - rowptr32[0])
+                if col32.data_ptr() not in clock.sources:     # distinct source rows referenced
+                    clock.sources[col32.data_ptr()] = int(torch.unique(col32).numel())
             if not clock.enabled:
                 return inner(rowptr32, col32, val, x, n_cols, *a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,6 +132,8 @@ class KernelClock:
         inner_inc = ops.spmm_csr_incagg
 
         def timed_inc(rowptr32, col32, val, x, m_in, m_ag, *a, **k):
+            if clock.counting and rowptr32.numel() > 1:
+                clock.edges += int(rowptr32[-1] - rowptr32[0])
             if not clock.enabled:
                 return inner_inc(rowptr32, col32, val, x, m_in, m_ag, *a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -133,8 +169,9 @@ def pmc_traffic(args):
     workload it was measured on and only while the kernel source is the one it was measured
     with (SHA-256 recorded next to it); otherwise null."""
     import hashlib
-    default = (args.dataset, args.parts, args.layers, args.hidden, args.scale, args.cross,
-               args.mode) == ("products", 150, 8, 256, 1.0, 0.15, "gas")
+    default = (args.dataset, args.parts, args.batch_parts, args.model, args.layers, args.hidden,
+               args.tables, args.scale, args.cross, args.mode) == \
+        ("products", 150, 1, "gcn2", 8, 256, "hbm", 1.0, 0.15, "gas")
     path = os.path.join(ROOT, "profiles", "pmc_traffic_current.json")
     src = os.path.join(ROOT, "incagg-gnn_amd", "csrc", "aggregate.hip")
     if not default or not os.path.isfile(path) or not os.path.isfile(src):
@@ -147,9 +184,18 @@ def pmc_traffic(args):
     return rec["traffic_bytes_per_launch"]
 
 
-def cpu_baseline(batches, layers, width, seconds):
-    """The CPU oracle's aggregation (forward + transposed) on the same batches, all host
-    cores the box grants (OMP), for about `seconds` of work."""
+def _transposed(rowptr, col, val, m):
+    b = rowptr.size - 1
+    order = np.argsort(col, kind="stable")
+    t_col = np.repeat(np.arange(b), np.diff(rowptr))[order].astype(np.int64)
+    t_rowptr = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(np.bincount(col, minlength=m), out=t_rowptr[1:])
+    return t_rowptr, t_col, val[order]
+
+
+def cpu_baseline_port(batches, layers, width, seconds):
+    """The C / OpenMP restatement of the CSR aggregation (oracle/aggregate_oracle.c), forward
+    + transposed, on the same batches, all host cores the box grants."""
     from oracle import cpu_path as cp
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     cp.set_threads(cores)
@@ -159,13 +205,7 @@ def cpu_baseline(batches, layers, width, seconds):
         b = rowptr.size - 1
         x = rng.standard_normal((m, width)).astype(np.float32)
         dy = rng.standard_normal((b, width)).astype(np.float32)
-        # transposed CSR for the backward aggregation (built outside the timed part)
-        order = np.argsort(col, kind="stable")
-        t_col = np.repeat(np.arange(b), np.diff(rowptr))[order].astype(np.int64)
-        t_val = val[order]
-        t_rowptr = np.zeros(m + 1, dtype=np.int64)
-        np.cumsum(np.bincount(col, minlength=m), out=t_rowptr[1:])
-        prepared.append((rowptr, col, val, x, t_rowptr, t_col, t_val, dy))
+        prepared.append((rowptr, col, val, x) + _transposed(rowptr, col, val, m) + (dy,))
     cp.spmm(*prepared[0][:4])  # warm
     while t_total < seconds:
         rowptr, col, val, x, t_rowptr, t_col, t_val, dy = prepared[used % len(prepared)]
@@ -180,6 +220,46 @@ def cpu_baseline(batches, layers, width, seconds):
             "sample": f"forward + transposed fp32 CSR aggregation of {used} partition-batch steps x "
                       f"{layers} layers at width {width} (dense updates, push/pull and optimizer "
                       f"not included), C/OpenMP oracle, {t_total:.1f} s"}
+
+
+def cpu_baseline(batches, layers, width, seconds, table_rows):
+    """The reference's CPU data path, restated with the operations the reference itself names
+    (its own SpMM lives in torch-sparse, which is not installed): per layer
+    `torch.sparse_csr_tensor(rowptr, col, val) @ x` forward and on the transposed matrix
+    backward (MKL, all granted host cores), the History pull `emb.index_select(0, n_id[B:])`
+    (history.py:38) and the chunk push `emb[o:o + c] = x[:B]` (history.py:63-65)."""
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1)
+    emb = torch.zeros(table_rows, width)
+    prepared = []
+    for rowptr, col, val, m, n_id, offset in batches:
+        b = rowptr.size - 1
+        t_rowptr, t_col, t_val = _transposed(rowptr, col, val, m)
+        a = torch.sparse_csr_tensor(torch.from_numpy(rowptr), torch.from_numpy(col),
+                                    torch.from_numpy(val), size=(b, m))
+        at = torch.sparse_csr_tensor(torch.from_numpy(t_rowptr), torch.from_numpy(t_col),
+                                     torch.from_numpy(t_val), size=(m, b))
+        prepared.append((a, at, torch.randn(m, width, generator=g), torch.randn(b, width, generator=g),
+                         n_id, int(offset), b, col.size))
+    _ = prepared[0][0] @ prepared[0][2]     # warm
+    edges, t_total, used = 0, 0.0, 0
+    while t_total < seconds:
+        a, at, x, dy, n_id, o, b, nnz = prepared[used % len(prepared)]
+        t0 = time.perf_counter()
+        for _ in range(layers):
+            y = a @ x                                   # aggregation
+            emb[o:o + b] = y                            # push of the fresh rows
+            _halo = emb.index_select(0, n_id[b:])       # pull of the out-of-batch rows
+            _dx = at @ dy                               # backward aggregation
+        t_total += time.perf_counter() - t0
+        edges += 2 * layers * nnz
+        used += 1
+    return {"value": edges / t_total, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{used} partition-batch steps x {layers} layers at width {width}: "
+                      "torch.sparse_csr_tensor @ x forward and transposed, History index_select "
+                      "pull and slice-assign push (history.py:38,63-65), dense updates and "
+                      f"optimizer not included; torch CPU ops on {cores} cores, {t_total:.1f} s"}
 
 
 def main():
@@ -203,7 +283,7 @@ def main():
 
     import torch_geometric_autoscale as tga
     from torch_geometric_autoscale import ops, _lib
-    from torch_geometric_autoscale.models import GCN2
+    from torch_geometric_autoscale.models import APPNP, GCN, GCN2, GraphSAGE
     from torch_geometric_autoscale.loader import partition_batch
     from torch_geometric_autoscale import distributed as D
 
@@ -229,43 +309,55 @@ def main():
     ctx = D.PartitionContext(ptr) if sharded else None
     parts_lo, parts_hi = rank * args.parts // world, (rank + 1) * args.parts // world
     my_parts = list(range(parts_lo, parts_hi))
-    need = min(args.parts // world, args.steps + args.warmup)
+    groups = [my_parts[i:i + args.batch_parts] for i in range(0, len(my_parts), args.batch_parts)]
+    need = min(len(groups), args.steps + args.warmup)
+    host_tables = args.tables == "host"
+    if host_tables and sharded:
+        raise SystemExit("bench.py: host-resident tables are measured on one GPU")
     loader_data = tga.Data(adj_t=data.adj_t, num_nodes=n)
     batches = []
-    for p in my_parts[:need]:
+    for grp in groups[:need]:
         if sharded:     # collective: builds the halo exchange plan of the batch
-            sub = D.sharded_partition_batch(loader_data, ptr, [p], ctx,
+            sub = D.sharded_partition_batch(loader_data, ptr, grp, ctx,
                                             in_batch_only=(args.mode == "vr"))
         else:
-            sub = partition_batch(loader_data, ptr, [p], in_batch_only=(args.mode == "vr"))
+            sub = partition_batch(loader_data, ptr, grp, in_batch_only=(args.mode == "vr"))
         adj = sub.data.adj_t.to(dev)
-        t_rowptr = adj.device_csr_t("sum")[0]       # backward CSR, once per batch
         nid_dev = sub.n_id.to(dev)
-        if args.mode == "gas" and nid_dev.numel() > sub.batch_size:
-            # column ids for reading out-of-batch rows in place from the History tables:
-            # part of batch construction, like the backward CSR
-            cip = adj.col_in_place(nid_dev[sub.batch_size:], sub.batch_size)
-            clock.sources[cip.data_ptr()] = int(nid_dev.numel())
-        e_all, e_ib = adj.nnz(), int(t_rowptr[sub.batch_size])
-        # edges aggregated per step: L forward aggregations over all E edges; backward:
-        # layer 0 over all E (its input is computed from features for every row), layers
-        # >= 1 only over edges whose source row is in the batch (pulled rows are constants)
-        if args.mode == "vr":
-            step_edges = 2 * args.layers * e_all
-        else:
-            step_edges = args.layers * e_all + e_all + (args.layers - 1) * e_ib
         batches.append({
             "adj": adj, "host": sub.data.adj_t, "b": sub.batch_size, "n_id": sub.n_id,
             "nid_dev": nid_dev, "offset": sub.offset, "count": sub.count,
-            "x": x_all[nid_dev], "y": y_all[nid_dev[:sub.batch_size]], "edges": step_edges,
+            "x": x_all[nid_dev], "y": y_all[nid_dev[:sub.batch_size]], "edges": 0,
         })
 
     table_rows = ctx.local_rows if sharded else n      # row-sharded tables, never replicated
-    model = GCN2(table_rows, f_in, args.hidden, n_cls, args.layers, alpha=0.1, theta=0.5,
-                 shared_weights=False, dropout=0.0, device=dev).to(dev)
+    table_dev = None if host_tables else dev
+    pool = {}
+    if host_tables:     # staging slots as main.py:177 sizes them: 2 x the largest batch (rows + halo)
+        from torch_geometric_autoscale import ops as _o
+        g_rowptr, g_col, _ = data.adj_t.csr()
+        largest = 0
+        for grp in groups:
+            idx = torch.cat([torch.arange(int(ptr[p_]), int(ptr[p_ + 1])) for p_ in grp])
+            largest = max(largest, int(_o.relabel_one_hop(g_rowptr, g_col, None, idx, True)[3].numel()))
+        pool = dict(pool_size=2, buffer_size=2 * largest)
+    if args.model == "gcn2":
+        model = GCN2(table_rows, f_in, args.hidden, n_cls, args.layers, alpha=0.1, theta=0.5,
+                     shared_weights=False, dropout=0.0, device=table_dev, **pool)
+    elif args.model == "gcn":
+        model = GCN(table_rows, f_in, args.hidden, n_cls, args.layers, dropout=0.0,
+                    drop_input=False, batch_norm=False, residual=False, device=table_dev, **pool)
+    elif args.model == "sage":
+        model = GraphSAGE(table_rows, f_in, args.hidden, n_cls, args.layers, dropout=0.0,
+                          drop_input=False, batch_norm=False, residual=False, device=table_dev,
+                          **pool)
+    else:
+        model = APPNP(table_rows, f_in, args.hidden, n_cls, args.layers, alpha=0.1, dropout=0.0,
+                      device=table_dev, **pool)
+    model = model.to(dev)
     if sharded:
         model.set_partition_context(ctx)
-    model.fused_incagg = not args.unfused_incagg
+    model.fused_incagg = args.fused_incagg
     g_cpu = torch.Generator().manual_seed(2)
     with torch.no_grad():
         for p_ in model.parameters():
@@ -274,8 +366,12 @@ def main():
                          (6.0 / (p_.size(0) + p_.size(1))) ** 0.5)
         for tables in (model.histories, model.histories_ag):   # non-trivial table contents
             for h in tables:
-                h.emb.normal_(0, 0.1, generator=g)
-    use_graphs = args.graphs == "on" or (args.graphs == "auto" and not sharded)
+                if h.emb.is_cuda:
+                    h.emb.normal_(0, 0.1, generator=g)
+                else:
+                    h.emb.normal_(0, 0.1)
+    # (staging pools run on side streams with a host worker thread: nothing to record)
+    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and not sharded)) and not host_tables
     # one launch per step; capturable: the step counter lives on the device
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graphs)
     crit = torch.nn.CrossEntropyLoss()
@@ -304,7 +400,17 @@ def main():
         opt.step()
         return bt["edges"]
 
+    # Edges per step, counted once per batch in an instrumented eager step: every aggregation
+    # launch adds the edges its rows address (forward launches the batch adjacency; backward
+    # launches the transposed adjacency, restricted to in-batch source rows where the
+    # out-of-batch rows are constants).  Also creates every lazily built per-batch structure.
     graphs = None
+    for k, bt in enumerate(batches):
+        clock.counting, clock.edges = True, 0
+        eager_step(k)
+        clock.counting = False
+        bt["edges"] = clock.edges
+    torch.cuda.synchronize()
     if use_graphs:
         # every batch's step is recorded once (untimed) and replayed from then on
         from torch_geometric_autoscale.graphs import StepGraphs
@@ -397,7 +503,7 @@ def main():
         if sharded:
             evals = D.sharded_eval_batches(feat, ptr, ctx)
         else:
-            evals = [partition_batch(feat, ptr, [p]) for p in range(args.parts)]
+            evals = [partition_batch(feat, ptr, grp) for grp in groups]
         for sub in evals:                       # features of each batch resident in HBM
             if sub.batch_size:
                 sub.data.x = x_all[sub.n_id.to(dev)]
@@ -418,16 +524,20 @@ def main():
     if rank == 0:
         bt = batches[0]
         line = {
-            "metric": "edges-aggregated/sec, ogbn-products GCN2 training step (forward + backward)",
+            "metric": f"edges-aggregated/sec, ogbn-{args.dataset} {MODEL_NAMES[args.model]} training "
+                      "step (forward + backward)",
             "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"GCN2 {args.layers}-layer hidden {args.hidden} on an ogbn-{args.dataset}-"
-                            f"sized synthetic graph (N={n}, nnz={data.adj_t.nnz()}), {args.parts} "
-                            f"partitions, one partition per step, {args.mode} training step, "
-                            "History tables resident in HBM",
+                "workload": f"{MODEL_NAMES[args.model]} {args.layers}-layer hidden {args.hidden} on "
+                            f"an ogbn-{args.dataset}-sized synthetic graph (N={n}, "
+                            f"nnz={data.adj_t.nnz()}), {args.parts} partitions, {args.batch_parts} "
+                            f"per step, {args.mode} training step, History tables "
+                            + ("in pinned host memory behind the staging pools" if host_tables
+                               else "resident in HBM"),
+                "preset": args.config,
                 "batch_rows": bt["b"], "batch_rows_with_halo": int(bt["n_id"].numel()),
                 "batch_edges": bt["adj"].nnz(),
                 "parallelism": f"partition-parallel x{world}" + (
@@ -438,10 +548,10 @@ def main():
                                 if graphs is not None else "eager"),
             },
             "epoch": {
-                "train_epoch_seconds": elapsed / args.steps * (args.parts // world),
+                "train_epoch_seconds": elapsed / args.steps * len(groups),
                 "refresh_sweep_seconds": sweep_s,
                 "refresh_sweep_edges_per_s": None if not sweep_s else sweep_edges / sweep_s,
-                "note": "training epoch = (partitions per GPU) x measured step time; the sweep is "
+                "note": "training epoch = (batches per GPU) x measured step time; the sweep is "
                         "one mini_inference_vr over this rank's partitions (forward only, both "
                         "History kinds refreshed)",
             },
@@ -461,8 +571,11 @@ def main():
             for b_ in batches[:4]:
                 rp, c, v = b_["host"].csr()
                 host.append((rp.numpy(), c.numpy(), v.numpy().astype(np.float32),
-                             int(b_["n_id"].numel())))
-            line["cpu_baseline"] = cpu_baseline(host, args.layers, args.hidden, args.cpu_seconds)
+                             int(b_["host"].size(1)), b_["n_id"], b_["offset"][0]))
+            agg_width = n_cls if args.model == "appnp" else args.hidden   # models/appnp.py:24
+            line["cpu_baseline"] = cpu_baseline(host, args.layers, agg_width, args.cpu_seconds, n)
+            line["cpu_baseline_c_port"] = cpu_baseline_port([h[:4] for h in host], args.layers,
+                                                            agg_width, args.cpu_seconds / 2)
         print(json.dumps(line), file=json_out, flush=True)
     if sharded:
         dist.destroy_process_group()

@@ -169,7 +169,10 @@ template <int VEC, int CH, bool INCAGG>
 __device__ __forceinline__ void accumulate_edges(const SpmmArgs &a, int rs, int re, int lane,
                                                  const int (&off)[CH],
                                                  typename VT<VEC>::type (&acc)[CH]) {
-  constexpr int UMAX = INCAGG ? 4 : 8;
+  // gathers in flight per wave: 8 rows of up to 1 KB; narrow unaligned rows (one float per
+  // lane, e.g. the 41 / 47-wide tables of APPNP) are cheap in registers and need more of them
+  // to keep the memory pipe busy
+  constexpr int UMAX = INCAGG ? 4 : (VEC == 1 && CH == 1 ? 32 : VEC == 1 && CH == 2 ? 16 : 8);
   for (int e0 = rs; e0 < re; e0 += kWave) {
     const int cnt = min(kWave, re - e0);
     int my_c = 0;
@@ -185,6 +188,14 @@ __device__ __forceinline__ void accumulate_edges(const SpmmArgs &a, int rs, int 
     }
     int j = 0;
     for (; j + UMAX <= cnt; j += UMAX) edge_step<VEC, CH, INCAGG, UMAX>(a, my_c, my_v, j, off, acc);
+    if (UMAX > 16 && j + 16 <= cnt) {
+      edge_step<VEC, CH, INCAGG, 16>(a, my_c, my_v, j, off, acc);
+      j += 16;
+    }
+    if (UMAX > 8 && j + 8 <= cnt) {
+      edge_step<VEC, CH, INCAGG, 8>(a, my_c, my_v, j, off, acc);
+      j += 8;
+    }
     if (UMAX > 4 && j + 4 <= cnt) {
       edge_step<VEC, CH, INCAGG, 4>(a, my_c, my_v, j, off, acc);
       j += 4;
