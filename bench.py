@@ -306,14 +306,12 @@ def main():
 
     # Rank r owns a contiguous block of partitions, i.e. a contiguous block of History rows;
     # every rank runs the same number of steps, each on one of its own partitions.
-    ctx = D.PartitionContext(ptr) if sharded else None
+    ctx = D.PartitionContext(ptr, exercise_collectives=args.force_dist) if sharded else None
     parts_lo, parts_hi = rank * args.parts // world, (rank + 1) * args.parts // world
     my_parts = list(range(parts_lo, parts_hi))
     groups = [my_parts[i:i + args.batch_parts] for i in range(0, len(my_parts), args.batch_parts)]
     need = min(len(groups), args.steps + args.warmup)
     host_tables = args.tables == "host"
-    if host_tables and sharded:
-        raise SystemExit("bench.py: host-resident tables are measured on one GPU")
     loader_data = tga.Data(adj_t=data.adj_t, num_nodes=n)
     batches = []
     for grp in groups[:need]:

@@ -35,8 +35,11 @@ class PartitionContext:
     """Who owns which partitions / History rows."""
 
     def __init__(self, ptr: Tensor, group=None, rank: Optional[int] = None,
-                 world: Optional[int] = None):
+                 world: Optional[int] = None, exercise_collectives: bool = False):
         self.group = group
+        # issue the all-to-all / all-reduce calls even when this is the only rank (they then
+        # move nothing): the communication path of a multi-GPU run on a single GPU
+        self.exercise_collectives = exercise_collectives
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.ptr = ptr
@@ -110,7 +113,7 @@ class HaloPlan:
         if n_own:
             ops.gather_rows(shard, own_local, out=out[:n_own], device=device)
         work = send = None
-        if self.ctx.world > 1:
+        if self.ctx.world > 1 or self.ctx.exercise_collectives:
             send = ops.gather_rows(shard, serve_local, device=device) if serve_local.numel() \
                 else torch.empty((0, f), dtype=shard.dtype, device=device)
             recv = out[n_own:self.n_halo]
@@ -222,7 +225,7 @@ def sharded_eval_batches(data: Data, ptr: Tensor, ctx: PartitionContext,
 def allreduce_gradients(module: torch.nn.Module, ctx: PartitionContext) -> None:
     """Mean of the weight gradients over the ranks, as ONE flat all-reduce (the models here
     have a few MB of parameters: a single bucket is the right granularity)."""
-    if ctx.world == 1:
+    if ctx.world == 1 and not ctx.exercise_collectives:
         return
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     if not grads:

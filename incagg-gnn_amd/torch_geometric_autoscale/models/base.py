@@ -189,14 +189,17 @@ class ScalableGNN(torch.nn.Module):
         self._async = (self.pool is not None and batch_size is not None and n_id is not None
                        and offset is not None and count is not None)
         if (batch_size is not None and not self._async and str(self.emb_device) == 'cpu'
-                and str(self.device)[:4] == 'cuda'):
+                and str(self.device)[:4] == 'cuda' and self.partition_ctx is None):
             warnings.warn('Asynchronous I/O disabled, although history and '
                           'model sit on different devices.')
 
         self._current_plan = getattr(adj_t, "_halo_plan", None)
         if self.partition_ctx is not None:
-            if self._async:
-                raise NotImplementedError("partition-parallel runs keep their table shards in HBM")
+            # Partition-parallel: a rank's table shard may also live in its pinned host memory.
+            # Rows then move by the row kernels reading / writing the pinned shard directly
+            # over the host link (own pushes, own out-of-batch rows, rows served to peers in
+            # front of the all-to-all); the staging ring is not used.
+            self._async = False
             if use_aggregation and self._current_plan is None and n_id is not None \
                     and n_id.numel() > (batch_size or 0):
                 raise RuntimeError("partition-parallel batches must come from "
@@ -239,9 +242,10 @@ class ScalableGNN(torch.nn.Module):
             return self.mini_inference(loader)
 
         self._async = (self.pool is not None and batch_size is not None and n_id is not None
-                       and offset is not None and count is not None)
+                       and offset is not None and count is not None
+                       and self.partition_ctx is None)
         if (batch_size is not None and not self._async and str(self.emb_device) == 'cpu'
-                and str(self.device)[:4] == 'cuda'):
+                and str(self.device)[:4] == 'cuda' and self.partition_ctx is None):
             warnings.warn('Asynchronous I/O disabled, although history and '
                           'model sit on different devices.')
 
@@ -525,13 +529,11 @@ class ScalableGNN(torch.nn.Module):
 
     def _sweep_layers(self, loader, use_aggregation: bool, with_aggregates: bool) -> Tensor:
         batches = [tuple(sub) + ({}, ) for sub in loader]
-        use_pool = self.pool is not None
+        sharded = self.partition_ctx is not None
+        use_pool = self.pool is not None and not sharded   # (sharded: see __call__)
         pool = self.pool if use_pool else None
         pool_ag = self.pool_ag if use_pool else None
         last = self.num_layers - 1
-        sharded = self.partition_ctx is not None
-        if sharded and use_pool:
-            raise NotImplementedError("partition-parallel runs keep their table shards in HBM")
         in_place = (self.halo_in_place and not use_pool and not sharded
                     and _same_device(self.emb_device, self.device))
 

@@ -98,3 +98,26 @@ if os.environ.get("SWEEP", "1") == "1":
             run(f"slices, plan {thr}/{seg}", 1, thr, seg)
 _lib.check_device_errors()
 print("done", flush=True)
+
+# ---- out-of-batch rows HBM-cold (as inside a training step: every layer reads another table),
+# with the edges of every row in storage order vs in-batch columns first
+if os.environ.get("COLD", "1") == "1":
+    tables = [torch.randn(N, F, device=dev) for _ in range(8)]
+    row = torch.repeat_interleave(torch.arange(B, device=dev), deg.to(torch.int64))
+    key = row * 2 + (c >= B).to(torch.int64)
+    perm = torch.argsort(key, stable=True)
+    c2, v2, cip2 = c[perm].contiguous(), v[perm].contiguous(), cip[perm].contiguous()
+    plan = ops.SpmmPlan.build(rp, E)
+    for label, cc, vv in (("storage order", cip, v), ("in-batch columns first", cip2, v2)):
+        k = [0]
+
+        def call():
+            k[0] += 1
+            return ops.spmm_csr(rp, cc, vv, xb, B + N, x_halo=tables[k[0] % 8], plan=plan)
+        ref = ops.spmm_csr(rp, cip, v, xb, B + N, x_halo=tables[1], plan=plan)
+        k[0] = 0
+        err = float((call() - ref).abs().max())
+        print(f"cold tables, {label}: {timeit(call):.1f} us (err {err:.1e})", flush=True)
+    for label, cc, vv in (("storage order", c, v), ("in-batch columns first", c2, v2)):
+        print(f"warm one source, {label}: {timeit(lambda: ops.spmm_csr(rp, cc, vv, x, M, plan=plan)):.1f} us",
+              flush=True)

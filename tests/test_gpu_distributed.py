@@ -1,0 +1,91 @@
+"""The partition-parallel code path on one MI355X over RCCL (backend "nccl", world size 1, the
+collectives issued although they move nothing): process-group set-up on the GPU, halo plans,
+`all_to_all_single` on device tensors, stream ordering of the pending exchange, the flat gradient
+all-reduce -- against the unsharded run of the same model.  Tables in HBM and in pinned host
+memory (BASELINE configuration 5's placement)."""
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+import model_cases as mc
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def rccl():
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=dev)
+    yield dev
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tables", ["hbm", "host"])
+@pytest.mark.parametrize("name", ["gcn2", "sage", "appnp"])
+def test_sharded_path_over_rccl_matches_unsharded(name, tables, rccl):
+    import torch_geometric_autoscale as tga
+    from torch_geometric_autoscale import _lib, distributed as D
+    from torch_geometric_autoscale.loader import partition_batch
+    dev = rccl
+    data, ptr = mc.make_graph()
+    f_in = data.x.size(1)
+
+    ref = mc.make_model(name, data, f_in, 5, emb_device=dev).to(dev)
+    ref.eval()
+    out_ref = ref.mini_inference_vr(tga.EvalSubgraphLoader(data, ptr, batch_size=1, log=False))
+
+    ctx = D.PartitionContext(ptr, exercise_collectives=True)
+    assert (ctx.rank, ctx.world, ctx.local_rows) == (0, 1, data.num_nodes)
+    emb_device = dev if tables == "hbm" else None
+    model = mc.make_model(name, data, f_in, 5, emb_device=emb_device, pool_size=2,
+                          buffer_size=4 * data.num_nodes if tables == "host" else None).to(dev)
+    model.load_state_dict(ref.state_dict())
+    model.set_partition_context(ctx)
+    if tables == "host":
+        assert model.histories[0].emb.is_pinned() and not model.histories[0].emb.is_cuda
+    model.eval()
+    batches = D.sharded_eval_batches(data, ptr, ctx, batch_size=1)
+    out = model.mini_inference_vr(batches)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), out_ref.cpu().numpy(), **TOL)
+    for i in range(model.num_layers):
+        # layer inputs are copies of computed rows; aggregates are sums in another order only
+        # where the halo rows arrive in plan order instead of first-seen order
+        np.testing.assert_allclose(model.histories[i].emb.cpu().numpy(),
+                                   ref.histories[i].emb.cpu().numpy(), **TOL)
+        np.testing.assert_allclose(model.histories_ag[i].emb.cpu().numpy(),
+                                   ref.histories_ag[i].emb.cpu().numpy(), **TOL)
+
+    # one push/pull training step and one incremental-aggregation step on a partition
+    model.train()
+    ref.train()
+    for vr in (False, True):
+        sub = D.sharded_partition_batch(data, ptr, [3], ctx, in_batch_only=vr)
+        sub_ref = partition_batch(data, ptr, [3], in_batch_only=vr)
+        b = sub.batch_size
+        outs, grads = [], []
+        for m, s in ((model, sub), (ref, sub_ref)):
+            call = m.VR_call if vr else m
+            o = call(s.data.x.to(dev), s.data.adj_t.to(dev), b, s.n_id, s.offset, s.count)["out"]
+            loss = torch.nn.functional.cross_entropy(o, s.data.y[:b].to(dev))
+            m.zero_grad()
+            loss.backward()
+            if m is model:
+                D.allreduce_gradients(m, ctx)
+            outs.append(o.detach().cpu().numpy())
+            grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()
+                                    if p.grad is not None]).cpu().numpy())
+        np.testing.assert_allclose(outs[0], outs[1], **TOL)
+        np.testing.assert_allclose(grads[0], grads[1], rtol=1e-3, atol=1e-5)
+    torch.cuda.synchronize()
+    _lib.check_device_errors()
