@@ -53,6 +53,31 @@ template <int VEC>
 __device__ __forceinline__ void stv(float *p, typename VT<VEC>::type v) {
   *reinterpret_cast<typename VT<VEC>::type *>(p) = v;
 }
+// max(0, v) per component when `on`, else v untouched (NaNs included)
+template <int VEC>
+__device__ __forceinline__ typename VT<VEC>::type vrelu(typename VT<VEC>::type v, bool on);
+template <>
+__device__ __forceinline__ float vrelu<1>(float v, bool on) { return on ? fmaxf(v, 0.f) : v; }
+template <>
+__device__ __forceinline__ f4 vrelu<4>(f4 v, bool on) {
+  f4 r;
+  r.x = on ? fmaxf(v.x, 0.f) : v.x; r.y = on ? fmaxf(v.y, 0.f) : v.y;
+  r.z = on ? fmaxf(v.z, 0.f) : v.z; r.w = on ? fmaxf(v.w, 0.f) : v.w;
+  return r;
+}
+// v where g > 0, else 0, per component
+template <int VEC>
+__device__ __forceinline__ typename VT<VEC>::type vgate(typename VT<VEC>::type v,
+                                                        typename VT<VEC>::type g);
+template <>
+__device__ __forceinline__ float vgate<1>(float v, float g) { return g > 0.f ? v : 0.f; }
+template <>
+__device__ __forceinline__ f4 vgate<4>(f4 v, f4 g) {
+  f4 r;
+  r.x = g.x > 0.f ? v.x : 0.f; r.y = g.y > 0.f ? v.y : 0.f;
+  r.z = g.z > 0.f ? v.z : 0.f; r.w = g.w > 0.f ? v.w : 0.f;
+  return r;
+}
 
 struct SpmmArgs {
   const int *rowptr;
@@ -78,6 +103,9 @@ struct SpmmArgs {
   float scale;
   float add_scale;
   int nnz;  // entries of col / val: a row pointer outside [0, nnz] is reported, not followed
+  int relu_x;           // source rows taken from x (not x2) pass through max(0, .) when gathered
+  const float *gate;    // y[i, :] is zeroed where gate[i, :] <= 0 (the backward of a relu)
+  long long ldgate;
   int *err;
   // plan (order == nullptr: rows in storage order, no items)
   const int *order;
@@ -144,8 +172,9 @@ __device__ __forceinline__ void edge_step(const SpmmArgs &a, int my_c, float my_
     const int c = __builtin_amdgcn_readlane(my_c, j + u);
     w[u] = readlane_f(my_v, j + u);
     const float *xr = c < a.split ? a.x + (size_t)c * a.ldx : a.x2 + (size_t)(c - a.split) * a.ldx2;
+    const bool relu = a.relu_x && c < a.split;
 #pragma unroll
-    for (int ch = 0; ch < CH; ch++) xv[u][ch] = ldv<VEC>(xr + off[ch]);
+    for (int ch = 0; ch < CH; ch++) xv[u][ch] = vrelu<VEC>(ldv<VEC>(xr + off[ch]), relu);
     if (INCAGG) {
       const float *mr = a.m_in + (size_t)c * a.ldin;
 #pragma unroll
@@ -237,6 +266,7 @@ __device__ __forceinline__ void store_row(const SpmmArgs &a, int row, float s,
       if (INCAGG) out += a.scale * ldv<VEC>(a.m_ag + (size_t)row * a.ldag + off[ch]);
       if (a.add) out += a.add_scale * ldv<VEC>(a.add + (size_t)row * a.ldadd + off[ch]);
     }
+    if (a.gate) out = vgate<VEC>(out, ldv<VEC>(a.gate + (size_t)row * a.ldgate + off[ch]));
     float *dst = a.y + (size_t)row * a.ldy + off[ch];
     if (!atomic) {
       stv<VEC>(dst, out);
@@ -372,12 +402,13 @@ __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float
     if constexpr (WIDE) {
       const float *xr = c[r] < a.split ? a.x + (size_t)c[r] * a.ldx
                                        : a.x2 + (size_t)(c[r] - a.split) * a.ldx2;
-      xv[r] = ldv<4>(xr + coloff);
+      xv[r] = vrelu<4>(ldv<4>(xr + coloff), a.relu_x && c[r] < a.split);
       if (INCAGG) mv[r] = ldv<4>(a.m_in + (size_t)c[r] * a.ldin + coloff);
     } else {
       // byte offsets computed in 32 bits: "scalar base + 32-bit lane offset" addressing
       const unsigned off = ((unsigned)c[r] * (unsigned)a.ldx + (unsigned)coloff) * 4u;
-      xv[r] = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.x) + off);
+      xv[r] = vrelu<4>(*reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.x) + off),
+                       a.relu_x != 0);
       if (INCAGG) {
         const unsigned moff = ((unsigned)c[r] * (unsigned)a.ldin + (unsigned)coloff) * 4u;
         mv[r] = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.m_in) + moff);
@@ -462,6 +493,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
       if (INCAGG) out += a.scale * ldv<4>(a.m_ag + (size_t)row * a.ldag + coloff);
       if (a.add) out += a.add_scale * ldv<4>(a.add + (size_t)row * a.ldadd + coloff);
     }
+    if (a.gate) out = vgate<4>(out, ldv<4>(a.gate + (size_t)row * a.ldgate + coloff));
     float *dst = a.y + (size_t)row * a.ldy + coloff;
     if (deg <= a.seg) {
       stv<4>(dst, out);
@@ -526,6 +558,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
     f4 out = acc * s;
     if (INCAGG) out += a.scale * ldv<4>(a.m_ag + (size_t)row * a.ldag + coloff);
     if (a.add) out += a.add_scale * ldv<4>(a.add + (size_t)row * a.ldadd + coloff);
+    if (a.gate) out = vgate<4>(out, ldv<4>(a.gate + (size_t)row * a.ldgate + coloff));
     stv<4>(a.y + (size_t)row * a.ldy + coloff, out);
   }
 }
@@ -709,8 +742,9 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
                                    int64_t ld_halo, int64_t n_split, int64_t n_rows,
                                    int64_t n_cols, int64_t width, int reduce, float scale,
                                    const float *add, int64_t ldadd, float add_scale,
-                                   int64_t nnz, const incagg_spmm_plan *plan, float *y,
-                                   int64_t ldy, void *stream) {
+                                   int64_t nnz, const incagg_spmm_plan *plan,
+                                   const incagg_spmm_fuse *fuse, float *y, int64_t ldy,
+                                   void *stream) {
   int rc = check_common(rowptr, col, x, ldx, n_rows, n_cols, width, reduce, add, ldadd, y, ldy, nnz);
   if (rc) return rc;
   if (n_rows == 0 || width == 0) return INCAGG_OK;
@@ -727,10 +761,18 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
   a.n_rows = (int)n_rows; a.n_cols = nnz > 0 ? (int)n_cols : 0; a.width = (int)width;
   a.mean = reduce == INCAGG_REDUCE_MEAN; a.scale = scale; a.add_scale = add_scale;
   a.nnz = (int)nnz;
+  if (fuse) {
+    INCAGG_REQUIRE(!fuse->gate || fuse->ld_gate >= width, "ld_gate %lld < width %lld",
+                   (long long)fuse->ld_gate, (long long)width);
+    INCAGG_REQUIRE((const void *)fuse->gate != (const void *)y, "y must not alias gate");
+    a.relu_x = fuse->relu_x != 0;
+    a.gate = fuse->gate;
+    a.ldgate = fuse->ld_gate;
+  }
   rc = error_flag_address(&a.err);
   if (rc) return rc;
   const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(x_halo, ld_halo) &&
-                    rows_vec4(add, ldadd) && rows_vec4(y, ldy);
+                    rows_vec4(add, ldadd) && rows_vec4(y, ldy) && rows_vec4(a.gate, a.ldgate);
   return dispatch_spmm<false>(a, vec4, plan, static_cast<hipStream_t>(stream));
 }
 

@@ -61,6 +61,13 @@ __global__ __launch_bounds__(256) void indexed_rows_kernel(float *table, long lo
   }
 }
 
+__device__ __forceinline__ float relu_of(float v) { return fmaxf(v, 0.f); }
+__device__ __forceinline__ f4 relu_of(f4 v) {
+  f4 r;
+  r.x = fmaxf(v.x, 0.f); r.y = fmaxf(v.y, 0.f); r.z = fmaxf(v.z, 0.f); r.w = fmaxf(v.w, 0.f);
+  return r;
+}
+
 constexpr int kMaxChunks = 32;
 
 struct ChunkTable {
@@ -74,7 +81,8 @@ struct ChunkTable {
 template <int VEC>
 __global__ __launch_bounds__(256) void chunk_rows_kernel(float *dst, long long ldd, int dst_width,
                                                         const float *src, long long lds,
-                                                        int src_width, const ChunkTable t) {
+                                                        int src_width, const ChunkTable t,
+                                                        int relu) {
   using V = typename RV<VEC>::type;
   const int lane = threadIdx.x & 63;
   const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6);
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(256) void chunk_rows_kernel(float *dst, long long l
       for (int u = 0; u < kRowsInFlight; u++) {
         v[u] = V(0.f);
         if (ok[u] && col < src_width) v[u] = *reinterpret_cast<const V *>(s[u] + col);
+        if (relu) v[u] = relu_of(v[u]);
       }
 #pragma unroll
       for (int u = 0; u < kRowsInFlight; u++)
@@ -163,7 +172,8 @@ extern "C" int incagg_copy_row_chunks_f32(float *dst, int64_t ldd, int64_t dst_r
                                           int64_t dst_width, const float *src, int64_t lds,
                                           int64_t src_rows, int64_t src_width,
                                           const int64_t *offset, const int64_t *count,
-                                          int64_t n_chunks, int packed_is_src, void *stream) {
+                                          int64_t n_chunks, int packed_is_src, int relu,
+                                          void *stream) {
   INCAGG_REQUIRE(n_chunks >= 0 && dst_width >= 0 && src_width >= 0, "bad size");
   INCAGG_REQUIRE(src_width <= dst_width && dst_width < INT_MAX,
                  "source rows (%lld wide) do not fit destination rows (%lld wide)",
@@ -203,10 +213,10 @@ extern "C" int incagg_copy_row_chunks_f32(float *dst, int64_t ldd, int64_t dst_r
     const int blocks = launch_blocks(t.first[t.n], kRowsInFlight);
     if (vec4)
       hipLaunchKernelGGL((chunk_rows_kernel<4>), dim3(blocks), dim3(256), 0, s, dst, (long long)ldd,
-                         (int)dst_width, src, (long long)lds, (int)src_width, t);
+                         (int)dst_width, src, (long long)lds, (int)src_width, t, relu);
     else
       hipLaunchKernelGGL((chunk_rows_kernel<1>), dim3(blocks), dim3(256), 0, s, dst, (long long)ldd,
-                         (int)dst_width, src, (long long)lds, (int)src_width, t);
+                         (int)dst_width, src, (long long)lds, (int)src_width, t, relu);
     INCAGG_HIP_TRY(hipGetLastError());
   }
   return INCAGG_OK;

@@ -20,7 +20,7 @@ SIGNATURES = {
     "incagg_device_count": (_int, []),
     "incagg_check_device_errors": (_int, []),
     "incagg_spmm_csr_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64,
-                                   _int, _f32, _vp, _i64, _f32, _i64, _vp, _vp, _i64, _vp]),
+                                   _int, _f32, _vp, _i64, _f32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "incagg_spmm_csr_incagg_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
                                           _i64, _int, _f32, _vp, _i64, _f32, _i64, _vp, _vp,
                                           _i64, _vp]),
@@ -38,7 +38,7 @@ SIGNATURES = {
     "incagg_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "incagg_scatter_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "incagg_copy_row_chunks_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp,
-                                          _i64, _int, _vp]),
+                                          _i64, _int, _int, _vp]),
     "incagg_stage_read_async": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
                                        _i64, _vp]),
     "incagg_stage_synchronize": (_int, []),
@@ -60,6 +60,11 @@ SIGNATURES = {
     "incagg_csr_transpose_device": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp,
                                            _vp, _vp, _vp]),
 }
+
+class SpmmFuseStruct(_c.Structure):
+    """``incagg_spmm_fuse`` of include/incagg_gnn.h."""
+    _fields_ = [("relu_x", _i32), ("gate", _vp), ("ld_gate", _i64)]
+
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1}
 ABI_VERSION = 2

@@ -64,7 +64,13 @@ class History(torch.nn.Module):
 
     @torch.no_grad()
     def push(self, x, n_id: Optional[Tensor] = None, offset: Optional[Tensor] = None,
-             count: Optional[Tensor] = None):
+             count: Optional[Tensor] = None, relu: bool = False):
+        """``relu``: ``x`` holds pre-activations and ``relu(x)`` is what gets stored (folded
+        into the chunk copy on the GPU path)."""
+        if relu and not (offset is not None and count is not None and x.is_cuda
+                         and self._gpu_path(True)):
+            x = torch.relu(x)
+            relu = False
         if n_id is None and x.size(0) != self.num_embeddings:
             raise ValueError
 
@@ -81,7 +87,7 @@ class History(torch.nn.Module):
         else:  # Push in chunks:
             if x.is_cuda and self._gpu_path(True):
                 ops.copy_row_chunks(self.emb, x if x.stride(-1) == 1 else x.contiguous(), offset,
-                                    count, packed_is_src=True, device=x.device)
+                                    count, packed_is_src=True, device=x.device, relu=relu)
             else:
                 src_o = 0
                 x = x.to(self.emb.device)

@@ -304,7 +304,7 @@ class ScalableGNN(torch.nn.Module):
 
     def _push_and_pull_split(self, history, x: Tensor, batch_size: Optional[int],
                              n_id: Optional[Tensor], offset: Optional[Tensor],
-                             count: Optional[Tensor]
+                             count: Optional[Tensor], relu: bool = False
                              ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
         """:meth:`push_and_pull` without the concatenation: returns the fresh in-batch rows
         and, separately, the out-of-batch rows (``None`` when there are none) plus, when
@@ -314,26 +314,28 @@ class ScalableGNN(torch.nn.Module):
         second piece is a view into slot memory that stays valid until
         :meth:`_release_halo`."""
         if n_id is None or batch_size is None:
+            assert not relu
             out, _ = self.push_and_pull(history, x, batch_size, n_id, offset, count)
             return out, None, None
         x = x if x.size(0) == batch_size else x[:batch_size]
         if self.partition_ctx is not None:
             # the local push; the out-of-batch rows were requested at the top of the step
             # (or are fetched now, when nothing was started: direct calls of this method)
-            history.push(x.detach(), n_id[:batch_size], self._local(offset), count)
+            history.push(x.detach(), n_id[:batch_size], self._local(offset), count, relu=relu)
             plan = self._current_plan
             if self._halo_pending:
                 return x, self._halo_pending.pop(0).wait(), None
             return x, (None if plan is None else plan.exchange(history.emb)), None
         if not self._async:
-            history.push(x.detach(), n_id[:batch_size], offset, count)
+            history.push(x.detach(), n_id[:batch_size], offset, count, relu=relu)
             if n_id.numel() <= batch_size:
                 return x, None, None
             if self._in_place_ok(history, x):
                 return x, history.emb[:, :x.size(1)], n_id[batch_size:]
             return x, history.pull(n_id[batch_size:]), None
         halo = self.pool.synchronize_pull()[:n_id.numel() - batch_size]
-        self.pool.async_push(x.detach(), offset, count, history.emb)
+        self.pool.async_push(torch.relu(x.detach()) if relu else x.detach(), offset, count,
+                             history.emb)
         self._halo_in_slot = True
         return x, halo, None
 
@@ -396,6 +398,13 @@ class ScalableGNN(torch.nn.Module):
         batch_size, n_id, offset, count = (tuple(args) + (None,) * 4)[:4]
         b = adj_t.size(0) if batch_size is None else batch_size
         state: Dict[str, Any] = {}
+        # Activation between two layers applied where its output is consumed (models that
+        # can: :meth:`_defers_relu`): `x` then holds pre-activations, the aggregation reads
+        # max(0, x), the History push stores max(0, x), and the aggregation's backward returns
+        # the gradient w.r.t. the pre-activations -- no pass of its own over the rows in
+        # either direction.
+        state['defer_relu'] = bool(use_aggregation and batch_size is not None
+                                   and n_id is not None and self._defers_relu())
         x = self._embed(x, state, b)
         if use_aggregation and not aggregate_combined:
             adj_t = in_batch_columns(adj_t, b)
@@ -407,6 +416,7 @@ class ScalableGNN(torch.nn.Module):
         halo = halo_ids = None
         # node ids where the tables live: one upload per batch object, not one per layer and step
         nid = None if n_id is None else _ids_on(adj_t, n_id, self.emb_device)
+        relu_pending = False
         for i in range(self.num_layers):
             x = self._layer_input(i, x)
             if not use_aggregation:
@@ -416,26 +426,40 @@ class ScalableGNN(torch.nn.Module):
                     halo = self._layer_input(i, halo)
                 mix = self._mix(i, state, b)
                 xa = self._pre_aggregate(i, x)
+                fuse = dict(relu_x=relu_pending,
+                            gate_grad=i == 0 and state.get('embed_grad_gated', False))
                 if mix is not None:
-                    agg = spmm(adj, x, self.agg_reduce, *mix, x_halo=halo, halo_ids=halo_ids)
+                    agg = spmm(adj, x, self.agg_reduce, *mix, x_halo=halo, halo_ids=halo_ids,
+                               **fuse)
                     h = self._update_mixed(i, agg, x, state)
                 elif xa is not None:
                     ha = None if halo is None else self._pre_aggregate(i, halo)
                     agg = spmm(adj, xa, reduce=self.agg_reduce, x_halo=ha)
                     h = self._update(i, agg, x, state, pre=True)
                 else:
-                    agg = spmm(adj, x, reduce=self.agg_reduce, x_halo=halo, halo_ids=halo_ids)
+                    agg = spmm(adj, x, reduce=self.agg_reduce, x_halo=halo, halo_ids=halo_ids,
+                               **fuse)
                     h = self._update(i, agg, x, state)
                 self._release_halo()
             if i < self.num_layers - 1:
                 if use_aggregation:
-                    x, halo, halo_ids = self._push_and_pull_split(self.histories[i + 1], h,
-                                                                  batch_size, nid, offset, count)
+                    relu_pending = state.pop('relu_deferred', False)
+                    x, halo, halo_ids = self._push_and_pull_split(
+                        self.histories[i + 1], h, batch_size, nid, offset, count,
+                        relu=relu_pending)
                 else:
                     x, _ = self.push_only(self.histories[i + 1], h, batch_size, nid, offset, count)
             else:
                 x = h
         return x, 0.0
+
+    def _defers_relu(self) -> bool:
+        """Models whose layers end in a relu that nothing but the next aggregation and the
+        History push consume may leave it to those two (see :meth:`forward`): when
+        ``state['defer_relu']`` is set they skip it in :meth:`_update` and set
+        ``state['relu_deferred']`` instead; an embedding whose relu backward the first
+        aggregation takes over sets ``state['embed_grad_gated']``."""
+        return False
 
     def VR_forward(self, x: Tensor, adj_t: SparseTensor, drift_norm: int = 2, epoch: int = 0,
                    batch_idx: int = 0, *args):

@@ -54,10 +54,19 @@ class GCN2(ScalableGNN):
             bn.reset_parameters()
 
     # ---- hooks (the per-layer arithmetic of models/gcn2.py:326-346)
+    def _defers_relu(self) -> bool:
+        # the relu at the end of a layer feeds the next aggregation and the History push only
+        # (no residual branch reads the layer input, no dropout sits in between)
+        return not self.residual and not (self.training and self.dropout > 0)
+
     def _embed(self, x: Tensor, state: Dict[str, Any], batch_size: int) -> Tensor:
         if self.drop_input:
             x = F.dropout(x, p=self.dropout, training=self.training)
-        x, state['x_0'] = embed_relu(self.lins[0], x, batch_size)
+        # with deferred activations the first aggregation's backward also applies the relu
+        # mask of the embedding to the gradient of all rows
+        gated = bool(state.get('defer_relu')) and torch.is_grad_enabled()
+        state['embed_grad_gated'] = gated
+        x, state['x_0'] = embed_relu(self.lins[0], x, batch_size, grad_gated=gated)
         # Training steps (one batch, all layers back to back): the x_0 terms of every layer in
         # one GEMM.  Not in the sweeps, where the per-batch state outlives the layer loop and
         # the terms of all batches would have to stay resident.
@@ -66,11 +75,14 @@ class GCN2(ScalableGNN):
             state['w1f'], state['x0_terms'] = gcn2_batched_terms(self.convs, state['x_0'])
         return F.dropout(x, p=self.dropout, training=self.training)
 
-    def _post(self, layer: int, h: Tensor, x: Tensor) -> Tensor:
+    def _post(self, layer: int, h: Tensor, x: Tensor, state: Dict[str, Any] = None) -> Tensor:
         if self.batch_norm:
             h = self.bns[layer](h)
         if self.residual and h.size(-1) == x.size(-1):
             h = h + (x if x.size(0) == h.size(0) else x[:h.size(0)])
+        if state is not None and state.get('defer_relu') and layer < self.num_layers - 1:
+            state['relu_deferred'] = True      # applied by the next aggregation and the push
+            return h
         h = h.relu_()
         if layer == self.num_layers - 1:
             h = F.dropout(h, p=self.dropout, training=self.training)
@@ -84,7 +96,7 @@ class GCN2(ScalableGNN):
                 agg, state['x_0'], state['w1f'][layer], state['x0_terms'][layer])
         else:
             h = self.convs[layer].forward_after_propagate(agg, state['x_0'])
-        return self._post(layer, h, x)
+        return self._post(layer, h, x, state)
 
     def _mix(self, layer: int, state: Dict[str, Any], batch_size: int):
         conv = self.convs[layer]
@@ -93,4 +105,4 @@ class GCN2(ScalableGNN):
         return 1.0 - conv.alpha, state['x_0'], conv.alpha
 
     def _update_mixed(self, layer: int, mixed: Tensor, x: Tensor, state: Dict[str, Any]) -> Tensor:
-        return self._post(layer, self.convs[layer].update_mixed(mixed), x)
+        return self._post(layer, self.convs[layer].update_mixed(mixed), x, state)

@@ -67,7 +67,8 @@ class _EmbedRelu(torch.autograd.Function):
     adding two full-size matrices."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, n_batch):
+    def forward(ctx, x, weight, bias, n_batch, grad_gated=False):
+        ctx.grad_gated = grad_gated
         if bias is not None and x.is_cuda:
             # bias and relu ride in the GEMM epilogue (hipBLASLt): 104 us instead of 145 us for
             # the 128k x 100 -> 256 embedding of a products batch
@@ -84,6 +85,10 @@ class _EmbedRelu(torch.autograd.Function):
         nb = ctx.n_batch
         if d_all is None:
             g = torch.zeros_like(h)
+        elif ctx.grad_gated:
+            # the consumer (the first aggregation's backward) zeroed it where h <= 0 already
+            # and hands over a buffer of its own: used in place
+            g = d_all if d_all.is_contiguous() else d_all.contiguous()
         else:
             g = torch.ops.aten.threshold_backward(d_all.contiguous(), h, 0)   # new tensor
         if d_batch is not None:
@@ -91,12 +96,14 @@ class _EmbedRelu(torch.autograd.Function):
         dx = g @ weight if ctx.needs_input_grad[0] else None
         dw = _tn_product(g, x) if ctx.needs_input_grad[1] else None
         db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def embed_relu(lin: Linear, x: Tensor, n_batch: int):
-    """``(relu(lin(x)), relu(lin(x))[:n_batch])`` through :class:`_EmbedRelu`."""
-    return _EmbedRelu.apply(x, lin.weight, lin.bias, n_batch)
+def embed_relu(lin: Linear, x: Tensor, n_batch: int, grad_gated: bool = False):
+    """``(relu(lin(x)), relu(lin(x))[:n_batch])`` through :class:`_EmbedRelu`.  ``grad_gated``:
+    the gradient arriving for the first output is already zeroed where the output is 0 (its
+    only consumer is an aggregation called with ``gate_grad=True``)."""
+    return _EmbedRelu.apply(x, lin.weight, lin.bias, n_batch, grad_gated)
 
 
 class _TwoTermUpdate(torch.autograd.Function):
@@ -264,27 +271,33 @@ class GCN2Conv(torch.nn.Module):
 
 
 def gcn2_batched_terms(convs, x_0: Tensor):
-    """For GCNII layers with separate weights: the folded first weights of ALL layers,
-    ``[L, C, C]``, and the ``x_0`` summands of all layers, a list of L ``[rows, C]`` matrices
-    cut from ONE ``[rows, C] x [C, L*C]`` product -- ``x_0`` is the same matrix in every layer
-    (models/gcn2.py:46-48), so its L small GEMMs (and, in the backward pass, L weight-gradient
-    GEMMs and L accumulations into ``d x_0``) collapse into one wide GEMM each."""
+    """For GCNII layers with separate weights: the folded first weights of ALL layers (a tuple
+    of L ``[C, C]`` matrices) and the ``x_0`` summands of all layers, a tuple of L ``[rows, C]``
+    matrices cut from ONE ``[rows, C] x [C, L*C]`` product -- ``x_0`` is the same matrix in
+    every layer (models/gcn2.py:46-48), so its L small GEMMs (and, in the backward pass, L
+    weight-gradient GEMMs and L accumulations into ``d x_0``) collapse into one wide GEMM each.
+    Folding ``scale * (beta W + (1 - beta) I)`` is one fused multiply-add per weight set over
+    constants built once; the per-layer pieces are handed out with ``unbind`` so that their
+    gradients come back as one stack instead of L zero-fill + copy + add rounds."""
     n_layers, c = len(convs), convs[0].channels
     dev, dt = x_0.device, x_0.dtype
-    consts = convs[0].__dict__.setdefault("_batched_consts", {})
-    if (dev, dt, n_layers) not in consts:   # built once: no host-to-device copy inside a step
-        consts[(dev, dt, n_layers)] = (
-            torch.tensor([conv.beta for conv in convs], device=dev, dtype=dt).view(-1, 1, 1),
-            torch.eye(c, device=dev, dtype=dt))
-    beta, eye = consts[(dev, dt, n_layers)]
     alpha = convs[0].alpha
-    w1 = torch.stack([conv.weight1 for conv in convs])
-    w2 = torch.stack([conv.weight2 for conv in convs])
-    w1f = (1.0 - alpha) * (beta * w1 + (1.0 - beta) * eye)
-    w2f = alpha * (beta * w2 + (1.0 - beta) * eye)
-    w2cat = w2f.permute(1, 0, 2).reshape(c, n_layers * c)
+    consts = convs[0].__dict__.setdefault("_batched_consts", {})
+    key = (dev, dt, n_layers, alpha)
+    if key not in consts:   # built once: no host-to-device copy inside a step
+        beta = torch.tensor([conv.beta for conv in convs], device=dev, dtype=dt)
+        eye = torch.eye(c, device=dev, dtype=dt)
+        consts[key] = (
+            ((1.0 - alpha) * (1.0 - beta)).view(-1, 1, 1) * eye,          # [L, C, C]
+            ((1.0 - alpha) * beta).view(-1, 1, 1).contiguous(),           # [L, 1, 1]
+            # second weight set laid out side by side, [C, L*C]: layer l in columns [lC, (l+1)C)
+            torch.cat([alpha * (1.0 - b) * eye for b in beta.tolist()], dim=1),
+            (alpha * beta).repeat_interleave(c).view(1, -1).contiguous())
+    c1, b1, c2cat, b2cat = consts[key]
+    w1f = torch.addcmul(c1, torch.stack([conv.weight1 for conv in convs]), b1)
+    w2cat = torch.addcmul(c2cat, torch.cat([conv.weight2 for conv in convs], dim=1), b2cat)
     terms = (x_0 @ w2cat).view(x_0.size(0), n_layers, c).unbind(1)
-    return w1f, terms
+    return w1f.unbind(0), terms
 
 
 class SAGEConv(torch.nn.Module):

@@ -137,11 +137,14 @@ def _plan_ref(plan: Optional[SpmmPlan], n_rows: int, dev):
 def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, n_cols: int,
              reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
              add_scale: float = 0.0, out: Optional[Tensor] = None,
-             x_halo: Optional[Tensor] = None, plan: Optional[SpmmPlan] = None) -> Tensor:
+             x_halo: Optional[Tensor] = None, plan: Optional[SpmmPlan] = None,
+             relu_x: bool = False, gate: Optional[Tensor] = None) -> Tensor:
     """y = scale * reduce_rows(A, [x ; x_halo]) + add_scale * add   (incagg_spmm_csr_f32).
 
     With ``x_halo`` the source rows ``[x.size(0), n_cols)`` are read from ``x_halo`` -- the
-    concatenation is never materialised.  ``plan``: :class:`SpmmPlan` of ``rowptr32``."""
+    concatenation is never materialised.  ``plan``: :class:`SpmmPlan` of ``rowptr32``.
+    ``relu_x``: rows of ``x`` (not of ``x_halo``) pass through ``max(0, .)`` as they are read;
+    ``gate`` ([n_rows, width]): the result is zeroed wherever ``gate <= 0``."""
     _need_cuda(x, "x")
     dev = x.device
     _rows_f32(x, "x")
@@ -177,12 +180,21 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
         _rows_f32(out, "out", dev)
         if out.size(0) != n_rows or out.size(1) != width:
             raise ValueError("out has the wrong shape")
+    fuse = None
+    if relu_x or gate is not None:
+        if gate is not None:
+            _rows_f32(gate, "gate", dev)
+            if gate.size(0) < n_rows or gate.size(1) != width:
+                raise ValueError("gate must be [>= n_rows, width]")
+        fuse_struct = _lib.SpmmFuseStruct(1 if relu_x else 0, _ptr(gate),
+                                          0 if gate is None else _ld(gate))
+        fuse = ctypes.addressof(fuse_struct)
     with torch.cuda.device(dev):
         check(lib().incagg_spmm_csr_f32(
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(x_halo),
             0 if x_halo is None else _ld(x_halo), n_split, n_rows, n_cols, width,
             REDUCE[reduce], float(scale), _ptr(add), 0 if add is None else _ld(add),
-            float(add_scale), int(col32.numel()), _plan_ref(plan, n_rows, dev), _ptr(out),
+            float(add_scale), int(col32.numel()), _plan_ref(plan, n_rows, dev), fuse, _ptr(out),
             _ld(out), _stream_of(dev)))
     return out
 
@@ -290,8 +302,9 @@ def _host_i64(t: Tensor, name: str) -> Tensor:
 
 
 def copy_row_chunks(dst: Tensor, src: Tensor, offset: Tensor, count: Tensor,
-                    packed_is_src: bool, device=None) -> None:
-    """Chunked row copy with zero padding (incagg_copy_row_chunks_f32)."""
+                    packed_is_src: bool, device=None, relu: bool = False) -> None:
+    """Chunked row copy with zero padding (incagg_copy_row_chunks_f32); ``relu``: the copied
+    values pass through ``max(0, .)``."""
     _rows_f32(dst, "dst")
     _rows_f32(src, "src")
     if not (_device_visible(dst) and _device_visible(src)):
@@ -307,7 +320,7 @@ def copy_row_chunks(dst: Tensor, src: Tensor, offset: Tensor, count: Tensor,
         check(lib().incagg_copy_row_chunks_f32(
             _ptr(dst), _ld(dst), dst.size(0), dst.size(1), _ptr(src), _ld(src), src.size(0),
             src.size(1), _ptr(offset), _ptr(count), offset.numel(), 1 if packed_is_src else 0,
-            _stream_of(dev)))
+            1 if relu else 0, _stream_of(dev)))
 
 
 # --------------------------------------------------------------------------- batch construction

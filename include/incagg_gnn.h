@@ -102,12 +102,25 @@ typedef struct incagg_spmm_plan {
   int32_t segment_edges;     /* edges per item, a multiple of 64 */
 } incagg_spmm_plan;
 
+/* Element-wise work of the surrounding layer folded into the launch (may be NULL):
+ *   relu_x   != 0: source rows taken from x (not from x_halo) pass through max(0, .) as they
+ *            are gathered -- the activation between two layers (models/gcn2.py:131-135,
+ *            models/gcn.py:144-148) applied where its output is consumed instead of in a pass
+ *            of its own (History rows are stored activated, see incagg_copy_row_chunks_f32);
+ *   gate     (device fp32 [n_rows, width], ld = ld_gate, or NULL): y[i, c] = 0 wherever
+ *            gate[i, c] <= 0 -- the backward of that activation, applied to dX = A^T dY. */
+typedef struct incagg_spmm_fuse {
+  int32_t relu_x;
+  const float *gate;
+  int64_t ld_gate;
+} incagg_spmm_fuse;
+
 int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                         const float *x, int64_t ldx, const float *x_halo, int64_t ld_halo,
                         int64_t n_split, int64_t n_rows, int64_t n_cols, int64_t width,
                         int reduce, float scale, const float *add, int64_t ldadd,
-                        float add_scale, int64_t nnz, const incagg_spmm_plan *plan, float *y,
-                        int64_t ldy, void *stream);
+                        float add_scale, int64_t nnz, const incagg_spmm_plan *plan,
+                        const incagg_spmm_fuse *fuse, float *y, int64_t ldy, void *stream);
 
 /*
  * Fused incremental aggregate (the fork's contribution):
@@ -218,12 +231,14 @@ int incagg_scatter_rows_f32(float *emb, int64_t lde, int64_t emb_rows,
  * Columns [src_width, dst_width) of every written row are zero-filled, which is
  * the zero-padding to the table width done in models/gcn.py:355-365,
  * models/graphsage.py:888-902, models/appnp.py:254-265.
+ * relu != 0: the copied values pass through max(0, .) (the layer's activation folded into
+ * the push of its output rows, see incagg_spmm_fuse).
  */
 int incagg_copy_row_chunks_f32(float *dst, int64_t ldd, int64_t dst_rows, int64_t dst_width,
                                const float *src, int64_t lds, int64_t src_rows,
                                int64_t src_width, const int64_t *offset,
                                const int64_t *count, int64_t n_chunks, int packed_is_src,
-                               void *stream);
+                               int relu, void *stream);
 
 /* ------------------------------------------------------------------ host <-> HBM staging
  * One process-wide worker thread runs queued reads in FIFO order

@@ -37,8 +37,10 @@ def _check_plan(plan, rowptr32):
 
 
 def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None, add_scale=0.0,
-              out=None, x_halo=None, plan=None):
+              out=None, x_halo=None, plan=None, relu_x=False, gate=None):
     _check_plan(plan, rowptr32)
+    if relu_x:
+        x = torch.relu(x)
     if x_halo is not None:
         x = torch.cat([x, x_halo], dim=0)
     y = cp.spmm(_np(rowptr32).astype(np.int64), _np(col32).astype(np.int64), _np(val),
@@ -46,6 +48,8 @@ def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None
     y = torch.from_numpy(y) * scale
     if add is not None:
         y = y + add_scale * add[:y.size(0)]
+    if gate is not None:
+        y = torch.where(gate[:y.size(0)] > 0, y, torch.zeros_like(y))
     if out is not None:
         out.copy_(y)
         return out
@@ -80,7 +84,9 @@ def _scatter_rows(emb, n_id, x):
     emb[n_id.cpu(), :x.size(1)] = x
 
 
-def _copy_row_chunks(dst, src, offset, count, packed_is_src, device=None):
+def _copy_row_chunks(dst, src, offset, count, packed_is_src, device=None, relu=False):
+    if relu:
+        src = torch.relu(src)
     s = 0
     w = src.size(1)
     for o, c in zip(offset.tolist(), count.tolist()):

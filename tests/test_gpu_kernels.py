@@ -468,3 +468,48 @@ def test_transposed_windows_width_256(dev, reduce, variant):
     halo = torch.randn(m - b, w, device=dev)
     tga.spmm(adj, xb, reduce, x_halo=halo).backward(dy)
     np.testing.assert_allclose(xb.grad.cpu().numpy(), want[:b], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("width", [256, 41])
+def test_spmm_fused_activation_and_gate(ops, dev, width, variant):
+    """relu applied to the fresh source rows as they are gathered (rows of x_halo untouched)
+    and the relu backward applied to the result (zero where gate <= 0), against the oracle on
+    the explicitly activated source and the explicitly masked result."""
+    from torch_geometric_autoscale import _lib
+    rng = np.random.default_rng(width + 5)
+    b, m = 300, 1500
+    rowptr, col, val = _straddling_batch(rng, b, m, {2: 200, 40: 1400})
+    x = rng.standard_normal((b, width)).astype(np.float32)
+    halo = rng.standard_normal((m - b, width)).astype(np.float32)
+    gate = rng.standard_normal((b + 3, width)).astype(np.float32)
+    gate[5] = 0.0                                      # zero counts as "not positive"
+    rp, c, v = _dev_csr(rowptr, col, val, dev)
+    xd, hd, gd = (torch.from_numpy(a).to(dev) for a in (x, halo, gate))
+    plan = _plan(variant, rp)
+    # split source: only the rows of x are activated
+    y64 = cp.spmm_f64(rowptr, col, val, np.concatenate([np.maximum(x, 0), halo]))
+    y = ops.spmm_csr(rp, c, v, xd, m, x_halo=hd, plan=plan, relu_x=True)
+    tol = tolerance(y64) + 1e-6 * np.sqrt(1400)
+    assert np.all(np.abs(y.cpu().numpy() - y64) <= tol)
+    # one source, activation and gate together
+    src = np.concatenate([x, halo])
+    y64 = cp.spmm_f64(rowptr, col, val, np.maximum(src, 0))
+    y64 = np.where(gate[:b] > 0, y64, 0.0)
+    y = ops.spmm_csr(rp, c, v, torch.from_numpy(src).to(dev), m, plan=plan, relu_x=True, gate=gd)
+    got = y.cpu().numpy()
+    assert np.all(np.abs(got - y64) <= tol)
+    assert np.all(got[gate[:b] <= 0] == 0.0)
+    _lib.check_device_errors()
+
+
+def test_chunk_push_with_activation(ops, dev):
+    rng = np.random.default_rng(12)
+    table = rng.standard_normal((900, 256)).astype(np.float32)
+    x = rng.standard_normal((300, 200)).astype(np.float32)
+    offset, count = np.array([600, 10], dtype=np.int64), np.array([100, 200], dtype=np.int64)
+    ref = table.copy()
+    cp.history_push(ref, np.pad(np.maximum(x, 0), ((0, 0), (0, 56))), np.arange(300), offset, count)
+    td = torch.from_numpy(table).to(dev)
+    ops.copy_row_chunks(td, torch.from_numpy(x).to(dev), torch.from_numpy(offset),
+                        torch.from_numpy(count), packed_is_src=True, relu=True)
+    assert np.array_equal(td.cpu().numpy(), ref)
