@@ -122,9 +122,11 @@ class KernelClock:
             # compulsory traffic: indices + weights, row pointers, every distinct source row
             # once, every destination row once (source rows touched <= n_cols)
             n_src = clock.sources.get(col32.data_ptr(), min(n_cols, nnz))
+            # (+ one read of the gate rows when the relu backward is fused into the epilogue)
+            n_out = n_rows * (2 if k.get("gate") is not None else 1)
             algo = nnz * (4 + (4 if val is not None else 0)) + (n_rows + 1) * 4 \
-                + n_src * f * 4 + n_rows * f * 4
-            gather = nnz * (f * 4 + 8) + n_rows * f * 4
+                + n_src * f * 4 + n_out * f * 4
+            gather = nnz * (f * 4 + 8) + n_out * f * 4
             clock.records.append((s, e, algo, gather, nnz))
             return y
 
@@ -464,20 +466,33 @@ def main():
     if graphs is not None:
         # The timed steps were graph replays, into which no timing events can be placed: the
         # per-launch durations come from an eager pass over the same K steps, right away.
-        # The events must bracket device time only: the stream is first given ~0.25 s of spin
-        # work, so that the host enqueues the whole pass ahead of the GPU and every start event
-        # is reached the moment the preceding kernel ends (an eager step takes the host longer
-        # to issue than the GPU to run; without the head start the intervals would include the
-        # host's time between recording the event and launching the kernel).
-        clock.enabled = True
-        torch.cuda._sleep(int(0.25 * 2.0e9))
+        # The events must bracket device time only.  An eager step takes the host longer to
+        # issue than the GPU to run, so every step is enqueued behind spin work that lasts
+        # 1.5x the host's issue time of a step: the GPU never catches up with the host, and every
+        # start event is reached the moment the preceding kernel ends (otherwise the intervals
+        # would include the host's time between recording the event and launching the kernel).
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        torch.cuda._sleep(20_000_000)
+        e.record()
+        torch.cuda.synchronize()
+        spin_per_ms = 20_000_000 / s.elapsed_time(e)
+        clock.enabled = True        # (issue time measured with the events in place)
+        t_issue = time.perf_counter()
+        eager_step(args.warmup % len(batches))
+        t_issue = (time.perf_counter() - t_issue) * 1e3
+        torch.cuda.synchronize()
+        clock.records.clear()
+        spin = int(spin_per_ms * 1.5 * t_issue)
         for i in range(args.steps):
+            torch.cuda._sleep(spin)
             eager_step((args.warmup + i) % len(batches))
         torch.cuda.synchronize()
         clock.enabled = False
         kernel_timing = ("HIP events around every aggregation launch in an eager pass over the "
-                         "same K steps run right after the timed region, enqueued behind 0.25 s "
-                         "of spin work so that the intervals hold device time only (the timed "
+                         "same K steps run right after the timed region, each step enqueued "
+                         f"behind {1.5 * t_issue:.1f} ms of spin work (1.5x the host's issue time of "
+                         "an eager step) so that the intervals hold device time only (the timed "
                          "steps are HIP graph replays, which cannot carry timing events)")
     if os.environ.get("BENCH_TRACE"):   # host-side enqueue time of every step
         print("enqueue ms/step:", " ".join(f"{(b - a) * 1e3:.2f}" for a, b in
