@@ -19,23 +19,53 @@ from .aggregate import spmm
 from .sparse import SparseTensor
 
 
+def _slab_count(rows: int) -> int:
+    """Number of row slabs for :func:`_tn_product`.  hipBLASLt's choice of kernel for the
+    batched product swings with the count (16k rows x 256 x 256 on MI355X: 46-51 us with 6, 8
+    or 9 slabs, 140-250 us with 16 to 32; 128k rows x 256 x 100: 72-77 us with 16, 32 or 64,
+    116 us with 8), so only counts measured to be good are used, preferring one that divides
+    ``rows`` (no remainder rows, i.e. no extra tiny GEMM)."""
+    good = (8, 9, 6) if rows < 65536 else (32, 64, 16)
+    for s in good:
+        if rows % s == 0:
+            return s
+    return good[0]
+
+
 def _tn_product(a: Tensor, b: Tensor) -> Tensor:
     """``a^T @ b`` for tall operands ([rows, m], [rows, n], rows >> m, n): the shape of every
     weight gradient here.  A [m, n] output gives a GEMM only a handful of tiles while the
     reduction runs over 10^4..10^5 rows, so the rows are cut into slabs that run as one
     batched product (8x / 32x the tiles) and are summed afterwards.  Measured on MI355X:
     16k rows x 256 x 256: 49 us with 8 slabs vs 107 us as one GEMM; 128k rows x 256 x 100:
-    77 us with 32 slabs, 123 us with 8, 376 us as one GEMM."""
+    77 us with 32 slabs, 123 us with 8, 376 us as one GEMM.  Rows may be strided (slices of a
+    wider matrix): nothing is copied."""
     rows = a.size(0)
-    slabs = 8 if rows < 65536 else 32
-    if rows < 4096 or a.dim() != 2:
+    if rows < 4096 or a.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
         return a.t() @ b
+    slabs = _slab_count(rows)
     k = (rows // slabs) * slabs
-    out = torch.bmm(a[:k].view(slabs, k // slabs, a.size(1)).transpose(1, 2),
-                    b[:k].view(slabs, k // slabs, b.size(1))).sum(0)
+    out = torch.bmm(a[:k].unflatten(0, (slabs, k // slabs)).transpose(1, 2),
+                    b[:k].unflatten(0, (slabs, k // slabs))).sum(0)
     if k < rows:
         out.addmm_(a[k:].t(), b[k:])
     return out
+
+
+def _column_sums(x: Tensor) -> Tensor:
+    """``x.sum(0)`` of a tall matrix (bias gradients) in two stages: 64 row slabs reduced side
+    by side, then the 64 partial rows.  torch's single reduction runs such shapes in 64
+    workgroups (16k x 47: 39 us -> 13 us; 128k x 256: 44 us -> 38 us on MI355X)."""
+    rows = x.size(0)
+    if rows < 4096 or x.dim() != 2:
+        return x.sum(0)
+    k = (rows // 64) * 64
+    if k == rows:
+        return x.unflatten(0, (64, k // 64)).sum(1).sum(0)
+    part = torch.empty((64 + rows - k, x.size(1)), dtype=x.dtype, device=x.device)
+    torch.sum(x[:k].unflatten(0, (64, k // 64)), dim=1, out=part[:64])
+    part[64:] = x[k:]           # the remainder rows join the second stage
+    return part.sum(0)
 
 
 class _RowsLinear(torch.autograd.Function):
@@ -55,7 +85,7 @@ class _RowsLinear(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dy @ weight if ctx.needs_input_grad[0] else None
         dw = _tn_product(dy, x) if ctx.needs_input_grad[1] else None
-        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = _column_sums(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
@@ -95,7 +125,7 @@ class _EmbedRelu(torch.autograd.Function):
             g[:nb] += torch.ops.aten.threshold_backward(d_batch.contiguous(), h[:nb], 0)
         dx = g @ weight if ctx.needs_input_grad[0] else None
         dw = _tn_product(g, x) if ctx.needs_input_grad[1] else None
-        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = _column_sums(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
 
 
@@ -107,14 +137,18 @@ def embed_relu(lin: Linear, x: Tensor, n_batch: int, grad_gated: bool = False):
 
 
 class _TwoTermUpdate(torch.autograd.Function):
-    """``h @ W1 + x0 @ W2`` (``x0`` / ``W2`` optional) with split-row weight gradients."""
+    """``h @ W1 + x0 @ W2`` (``x0`` / ``W2`` optional) with split-row weight gradients.
+    ``term``: the second summand ready-made; the product is then accumulated INTO it (the GEMM
+    reads and writes the same matrix: no copy of the summand in front of it) and it is the
+    result."""
 
     @staticmethod
     def forward(ctx, h, w1, x0, w2, term=None):
         ctx.save_for_backward(h, w1, x0, w2)
         ctx.has_term = term is not None
-        if term is not None:        # the second summand arrives ready-made
-            return torch.addmm(term, h, w1)
+        if term is not None:
+            ctx.mark_dirty(term)
+            return term.addmm_(h, w1)
         if x0 is None:
             return h @ w1
         return torch.addmm(x0 @ w2, h, w1)
@@ -122,7 +156,8 @@ class _TwoTermUpdate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         h, w1, x0, w2 = ctx.saved_tensors
-        dy = dy.contiguous()
+        if dy.stride(-1) != 1:
+            dy = dy.contiguous()
         dh = dy @ w1.t() if ctx.needs_input_grad[0] else None
         dw1 = _tn_product(h, dy) if ctx.needs_input_grad[1] else None
         dx0 = dw2 = None
@@ -131,6 +166,45 @@ class _TwoTermUpdate(torch.autograd.Function):
             dw2 = _tn_product(x0, dy) if ctx.needs_input_grad[3] else None
         dterm = dy if ctx.has_term and ctx.needs_input_grad[4] else None
         return dh, dw1, dx0, dw2, dterm
+
+
+class _X0Terms(torch.autograd.Function):
+    """``x_0 @ [W_1 | ... | W_L]`` handed out as the L column blocks ``[rows, C]`` of ONE
+    ``[rows, L*C]`` matrix.  ``grad_stack``: a matrix of that shape whose column blocks the
+    producers of the blocks' gradients may have written in place (see
+    :func:`~torch_geometric_autoscale.aggregate.spmm`, ``grad_out``); gradients that arrive
+    elsewhere are copied into their block, and the two wide backward GEMMs run on the stack
+    without concatenating anything."""
+
+    @staticmethod
+    def forward(ctx, x_0, wcat, n_layers, grad_stack):
+        buf = x_0 @ wcat
+        c = wcat.size(1) // n_layers
+        ctx.save_for_backward(x_0, wcat)
+        ctx.grad_stack, ctx.c = grad_stack, c
+        # .data: a version counter per block.  The blocks never overlap and every consumer
+        # updates its own one in place; with the counter of `buf` shared among them, what
+        # another consumer saved of ITS block would count as modified.
+        return tuple(buf[:, i * c:(i + 1) * c].data for i in range(n_layers))
+
+    @staticmethod
+    def backward(ctx, *dterms):
+        x_0, wcat = ctx.saved_tensors
+        c, stack = ctx.c, ctx.grad_stack
+        rows = x_0.size(0)
+        if stack is not None and tuple(stack.shape) == (rows, c * len(dterms)):
+            for i, g in enumerate(dterms):
+                blk = stack[:, i * c:(i + 1) * c]
+                if g is None:
+                    blk.zero_()
+                elif g.data_ptr() != blk.data_ptr() or g.stride() != blk.stride():
+                    blk.copy_(g)
+            d = stack
+        else:
+            d = torch.cat([x_0.new_zeros(rows, c) if g is None else g for g in dterms], dim=1)
+        dx0 = d @ wcat.t() if ctx.needs_input_grad[0] else None
+        dw = _tn_product(x_0, d) if ctx.needs_input_grad[1] else None
+        return dx0, dw, None, None
 
 
 class RowsLinear(Linear):
@@ -270,15 +344,16 @@ class GCN2Conv(torch.nn.Module):
         return self.forward_after_propagate(spmm(adj_t, x), x_0)
 
 
-def gcn2_batched_terms(convs, x_0: Tensor):
+def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
     """For GCNII layers with separate weights: the folded first weights of ALL layers (a tuple
     of L ``[C, C]`` matrices) and the ``x_0`` summands of all layers, a tuple of L ``[rows, C]``
     matrices cut from ONE ``[rows, C] x [C, L*C]`` product -- ``x_0`` is the same matrix in
     every layer (models/gcn2.py:46-48), so its L small GEMMs (and, in the backward pass, L
     weight-gradient GEMMs and L accumulations into ``d x_0``) collapse into one wide GEMM each.
     Folding ``scale * (beta W + (1 - beta) I)`` is one fused multiply-add per weight set over
-    constants built once; the per-layer pieces are handed out with ``unbind`` so that their
-    gradients come back as one stack instead of L zero-fill + copy + add rounds."""
+    constants built once; the folded first weights are handed out with ``unbind`` so that their
+    gradients come back as one stack instead of L zero-fill + copy + add rounds, the ``x_0``
+    summands by :class:`_X0Terms` (``grad_stack``: see there)."""
     n_layers, c = len(convs), convs[0].channels
     dev, dt = x_0.device, x_0.dtype
     alpha = convs[0].alpha
@@ -296,8 +371,7 @@ def gcn2_batched_terms(convs, x_0: Tensor):
     c1, b1, c2cat, b2cat = consts[key]
     w1f = torch.addcmul(c1, torch.stack([conv.weight1 for conv in convs]), b1)
     w2cat = torch.addcmul(c2cat, torch.cat([conv.weight2 for conv in convs], dim=1), b2cat)
-    terms = (x_0 @ w2cat).view(x_0.size(0), n_layers, c).unbind(1)
-    return w1f.unbind(0), terms
+    return w1f.unbind(0), _X0Terms.apply(x_0, w2cat, n_layers, grad_stack)
 
 
 class SAGEConv(torch.nn.Module):
