@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--fused-incagg", action="store_true",
                     help="vr mode: A (x - M_in) + M_ag as one launch gathering both operands "
                          "(default: x - M_in as a pass of its own, then the plain aggregation)")
+    ap.add_argument("--epoch-pass", choices=["auto", "on", "off"], default="auto",
+                    help="after the timed steps, time one training pass over ALL of this rank's "
+                         "partition batches (auto: single-GPU runs)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay every step from a HIP graph recorded once per batch "
                          "(auto: on for a single GPU)")
@@ -312,7 +315,8 @@ def main():
     parts_lo, parts_hi = rank * args.parts // world, (rank + 1) * args.parts // world
     my_parts = list(range(parts_lo, parts_hi))
     groups = [my_parts[i:i + args.batch_parts] for i in range(0, len(my_parts), args.batch_parts)]
-    need = min(len(groups), args.steps + args.warmup)
+    epoch_pass = args.epoch_pass == "on" or (args.epoch_pass == "auto" and not sharded)
+    need = len(groups) if epoch_pass else min(len(groups), args.steps + args.warmup)
     host_tables = args.tables == "host"
     loader_data = tga.Data(adj_t=data.adj_t, num_nodes=n)
     batches = []
@@ -494,6 +498,20 @@ def main():
                          f"behind {1.5 * t_issue:.1f} ms of spin work (1.5x the host's issue time of "
                          "an eager step) so that the intervals hold device time only (the timed "
                          "steps are HIP graph replays, which cannot carry timing events)")
+    # ---- epoch time, part (i): one training pass over every partition batch of this rank
+    # (outside the timed region; the same step() the K timed steps ran)
+    epoch_s = None
+    if epoch_pass and len(batches) == len(groups):
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+        t_ep = time.perf_counter()
+        for i in range(len(batches)):
+            step(i)
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+        epoch_s = time.perf_counter() - t_ep
     if os.environ.get("BENCH_TRACE"):   # host-side enqueue time of every step
         print("enqueue ms/step:", " ".join(f"{(b - a) * 1e3:.2f}" for a, b in
                                              zip(host_marks, host_marks[1:])), file=sys.stderr)
@@ -561,10 +579,14 @@ def main():
                                 if graphs is not None else "eager"),
             },
             "epoch": {
-                "train_epoch_seconds": elapsed / args.steps * len(groups),
+                "train_epoch_seconds": epoch_s if epoch_s is not None
+                else elapsed / args.steps * len(groups),
+                "train_epoch_measured": epoch_s is not None,
+                "train_epoch_batches": len(groups),
                 "refresh_sweep_seconds": sweep_s,
                 "refresh_sweep_edges_per_s": None if not sweep_s else sweep_edges / sweep_s,
-                "note": "training epoch = (batches per GPU) x measured step time; the sweep is "
+                "note": "training epoch = one measured pass over all of this rank's partition "
+                        "batches (when train_epoch_measured; else batches x step time); the sweep is "
                         "one mini_inference_vr over this rank's partitions (forward only, both "
                         "History kinds refreshed)",
             },
