@@ -40,6 +40,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kSliceFloats = 32;  // 128-byte feature slices
+constexpr int kCombineWidth = 1024;                                // widest row the slices cover
+constexpr int kCombineSlot = kCombineWidth + kCombineWidth / kSliceFloats;
+static_assert(kCombineSlot == INCAGG_SPMM_COMBINE_SLOT_FLOATS, "header and kernel disagree");
 
 template <int VEC> struct VT;
 template <> struct VT<1> { using type = float; };
@@ -113,6 +116,11 @@ struct SpmmArgs {
   int n_hub;    // the first n_hub entries of `order` are covered by `items`
   int n_items;
   int seg;      // edges per item
+  // rows cut into several segments: their ids and, when the plan brings one, the combine
+  // buffer (kCombineSlot floats per such row: accumulators, then one arrival counter per slice)
+  const int *multi_rows;
+  int n_multi;
+  float *comb;
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -485,7 +493,21 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
     acc += shfl_xor4(acc, 32);
     if (g == 0) part[wave][t] = acc;
     __syncthreads();
-    if (wave != 0 || g != 0 || !live) return;
+    if (wave != 0) return;
+    const bool multi = deg > a.seg;
+    int slot = -1;
+    if (multi && a.comb) {  // which of the plan's multi-segment rows this is (wave-uniform)
+      for (int base = 0; base < a.n_multi && slot < 0; base += kWave) {
+        const int idx = base + lane;
+        const unsigned long long hit = __ballot(idx < a.n_multi && a.multi_rows[idx] == row);
+        if (hit) slot = base + __ffsll((long long)hit) - 1;
+      }
+      if (slot < 0) {  // not in the list: reported, row left alone
+        *a.err = 1;
+        return;
+      }
+    }
+    if (g != 0 || !live) return;
     acc = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
     const float s = a.scale * (a.mean ? 1.0f / (float)max(deg, 1) : 1.0f);
     f4 out = acc * s;
@@ -495,8 +517,31 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
     }
     if (a.gate) out = vgate<4>(out, ldv<4>(a.gate + (size_t)row * a.ldgate + coloff));
     float *dst = a.y + (size_t)row * a.ldy + coloff;
-    if (deg <= a.seg) {
+    if (!multi) {
       stv<4>(dst, out);
+    } else if (a.comb) {
+      // Segments of one row meet in the plan's combine buffer, which is all zero between
+      // launches: every segment adds its part, then counts its arrival; the last one to
+      // arrive takes the totals out (leaving zeros behind), clears the counter and writes the
+      // row.  The adds return their old values: a returned value means the add has been
+      // performed at the device-wide coherence point, so waiting for them orders the adds
+      // in front of the arrival count without a release fence (which would write the XCD's
+      // whole L2 back).
+      float *accp = a.comb + (size_t)slot * kCombineSlot + coloff;
+      const float r0 = atomicAdd(accp, out.x), r1 = atomicAdd(accp + 1, out.y);
+      const float r2 = atomicAdd(accp + 2, out.z), r3 = atomicAdd(accp + 3, out.w);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
+      int *cnt = reinterpret_cast<int *>(a.comb + (size_t)slot * kCombineSlot + kCombineWidth) + slice;
+      int prev = 0;
+      if (t == 0) prev = atomicAdd(cnt, 1);
+      prev = rfl(prev);   // (lane 0 is live and active: the first active lane)
+      if (prev == (deg + a.seg - 1) / a.seg - 1) {
+        f4 tot;
+        tot.x = atomicExch(accp, 0.f); tot.y = atomicExch(accp + 1, 0.f);
+        tot.z = atomicExch(accp + 2, 0.f); tot.w = atomicExch(accp + 3, 0.f);
+        if (t == 0) atomicExch(cnt, 0);
+        stv<4>(dst, tot);
+      }
     } else {  // several segments add onto the row, zeroed in front of this launch
       atomicAdd(dst, out.x);
       atomicAdd(dst + 1, out.y);
@@ -623,6 +668,9 @@ static int bind_plan(SpmmArgs &a, const incagg_spmm_plan *plan) {
   a.items = nullptr;
   a.n_hub = a.n_items = 0;
   a.seg = INT_MAX;
+  a.multi_rows = nullptr;
+  a.n_multi = 0;
+  a.comb = nullptr;
   if (!plan) return INCAGG_OK;
   INCAGG_REQUIRE(plan->order != nullptr, "plan without a row order");
   INCAGG_REQUIRE(plan->n_rows == a.n_rows, "plan was built for %lld rows, the call has %d",
@@ -640,6 +688,9 @@ static int bind_plan(SpmmArgs &a, const incagg_spmm_plan *plan) {
   a.n_hub = (int)plan->n_hub;
   a.n_items = (int)plan->n_items;
   a.seg = plan->segment_edges;
+  a.multi_rows = plan->multi_rows;
+  a.n_multi = (int)plan->n_multi;
+  INCAGG_REQUIRE(plan->combine == nullptr || plan->combine_floats >= 0, "negative combine size");
   return INCAGG_OK;
 }
 
@@ -668,7 +719,12 @@ static int launch_rows(SpmmArgs &a, const incagg_spmm_plan *plan, hipStream_t st
 
 template <bool INCAGG>
 static int launch_sliced(SpmmArgs &a, const incagg_spmm_plan *plan, hipStream_t stream) {
-  int rc = launch_zero(a, plan, stream);
+  // with a combine buffer (large enough, 16-byte aligned) the multi-segment rows need no
+  // zeroing launch
+  if (plan && plan->n_multi > 0 && plan->combine && aligned16(plan->combine) &&
+      plan->combine_floats >= plan->n_multi * (int64_t)kCombineSlot && a.width <= kCombineWidth)
+    a.comb = plan->combine;
+  int rc = a.comb ? INCAGG_OK : launch_zero(a, plan, stream);
   if (rc) return rc;
   const int n_slices = (a.width + kSliceFloats - 1) / kSliceFloats;
   const long long rows_per_block = kWavesPerBlock * 8;

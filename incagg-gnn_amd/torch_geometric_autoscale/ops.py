@@ -54,7 +54,12 @@ class SpmmPlan:
     built once per adjacency at batch construction -- on the host for host-built batches
     (then uploaded), on the GPU for device-built ones -- and passed to every aggregation call
     over those row pointers.  The arrays are never replaced once built: recorded HIP graphs
-    hold their addresses."""
+    hold their addresses.
+
+    A plan on the GPU with rows cut into several segments also owns their ``combine`` buffer
+    (where the segments of such a row meet; all zero between launches).  It makes the plan
+    stateful: launches that use one plan must not overlap in time (one stream, or ordered
+    streams); ``combine = None`` falls back to zeroing those rows with a launch in front."""
 
     def __init__(self, order: Tensor, items: Tensor, multi_rows: Tensor, n_hub: int,
                  n_items: int, n_multi: int, hub_threshold: int, segment_edges: int):
@@ -62,6 +67,10 @@ class SpmmPlan:
         self.n_rows = int(order.numel())
         self.n_hub, self.n_items, self.n_multi = int(n_hub), int(n_items), int(n_multi)
         self.hub_threshold, self.segment_edges = int(hub_threshold), int(segment_edges)
+        self.combine = None
+        if order.is_cuda and self.n_multi > 0:
+            self.combine = torch.zeros(self.n_multi * _lib.COMBINE_SLOT_FLOATS,
+                                       dtype=torch.float32, device=order.device)
         self._struct = None
 
     @property
@@ -81,8 +90,16 @@ class SpmmPlan:
         if self._struct is None:
             self._struct = _lib.SpmmPlanStruct(
                 _ptr(self.order), _ptr(self.items), _ptr(self.multi_rows), self.n_rows,
-                self.n_hub, self.n_items, self.n_multi, self.hub_threshold, self.segment_edges)
+                self.n_hub, self.n_items, self.n_multi, self.hub_threshold, self.segment_edges,
+                _ptr(self.combine), 0 if self.combine is None else self.combine.numel())
         return self._struct
+
+    def without_combine(self) -> "SpmmPlan":
+        """The same plan (same arrays) without the combine buffer."""
+        twin = SpmmPlan(self.order, self.items, self.multi_rows, self.n_hub, self.n_items,
+                        self.n_multi, self.hub_threshold, self.segment_edges)
+        twin.combine = None
+        return twin
 
     @staticmethod
     def build(rowptr32: Tensor, nnz: Optional[int] = None, hub_threshold: int = 0,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INCAGG_ABI_VERSION 2
+#define INCAGG_ABI_VERSION 3
 
 enum {
   INCAGG_OK = 0,
@@ -83,9 +83,10 @@ int incagg_check_device_errors(void);
  *   width <= 1024 when every pointer is 16-byte aligned and every ld a multiple
  *   of 4, else width <= 256.
  *
- * One launch per call (two when the plan holds rows cut into several segments: those rows are
- * zeroed first and their segments combined with fp32 atomics; every other row is written by
- * exactly one wave with a fixed summation order, i.e. bit-reproducibly).  Two kernels, chosen
+ * One launch per call.  Rows cut into several segments are combined with fp32 atomics, in the
+ * plan's combine buffer or, without one, on the output row, which a small launch in front then
+ * zeroes; every other row is written by exactly one wave with a fixed summation order, i.e.
+ * bit-reproducibly.  Two kernels, chosen
  * by alignment: 128-byte feature slices pinned to one XCD each so that every source byte has a
  * single home L2, 8 short rows per wave; or whole rows per wave (any width / alignment).  The
  * call allocates nothing, keeps no state between calls and may be recorded into a HIP graph.
@@ -100,7 +101,16 @@ typedef struct incagg_spmm_plan {
   int64_t n_multi;
   int32_t hub_threshold;
   int32_t segment_edges;     /* edges per item, a multiple of 64 */
+  /* Optional: where the segments of the multi-segment rows meet.  Device fp32, 16-byte aligned,
+   * n_multi * INCAGG_SPMM_COMBINE_SLOT_FLOATS entries, ALL ZERO when handed over; every launch
+   * leaves it all zero again.  With it the 16-byte-aligned kernel needs no zeroing launch in
+   * front (one launch per call, always).  It is state of the plan: calls that use the same
+   * plan must not overlap in time, and a launch that is aborted half-way leaves it dirty
+   * (clear it before the plan is used again).  NULL: rows are zeroed by a launch in front. */
+  float *combine;
+  int64_t combine_floats;
 } incagg_spmm_plan;
+#define INCAGG_SPMM_COMBINE_SLOT_FLOATS 1056 /* 1024 accumulators + 32 per-slice arrival counters */
 
 /* Element-wise work of the surrounding layer folded into the launch (may be NULL):
  *   relu_x   != 0: source rows taken from x (not from x_halo) pass through max(0, .) as they

@@ -28,7 +28,7 @@ def ops():
 
 
 @pytest.fixture(params=["rows", "rows_plan", "sliced", "sliced_plan", "sliced_short_segments",
-                        "rows_short_segments"])
+                        "sliced_short_segments_zeroed", "rows_short_segments"])
 def variant(request):
     """Forces one aggregation kernel (whole rows per wave / 128-byte feature slices) and one
     kind of work plan: none (rows in storage order, every row by one wave or lane group), the
@@ -46,6 +46,8 @@ def _plan(variant, rowptr32):
         return _ops.SpmmPlan.build(rowptr32)
     if variant.endswith("_short_segments"):
         return _ops.SpmmPlan.build(rowptr32, hub_threshold=24, segment_edges=128)
+    if variant.endswith("_short_segments_zeroed"):   # no combine buffer: zeroing launch in front
+        return _ops.SpmmPlan.build(rowptr32, hub_threshold=24, segment_edges=128).without_combine()
     return None
 
 
@@ -117,6 +119,33 @@ def test_spmm_hub_rows_sliced(ops, dev, variant):
     y2 = ops.spmm_csr(rp, c, v, torch.from_numpy(x).to(dev), n_cols, "mean",
                       plan=_plan(variant, rp))
     assert torch.allclose(y, y2, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("width", [256, 128, 36, 1024])
+def test_spmm_combine_buffer_is_left_clean(ops, dev, width):
+    """Rows cut into several segments meet in the plan's combine buffer: many launches in a row
+    over ONE plan (different widths use different parts of it) give the result of the zeroing
+    path, into an output full of garbage, and every launch leaves the buffer all zero."""
+    rng = np.random.default_rng(12)
+    n_rows, n_cols = 40, 3000
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, 10, hubs={3: 700, 11: 2999, 39: 130})
+    x = rng.standard_normal((n_cols, width)).astype(np.float32)
+    add = rng.standard_normal((n_rows, width)).astype(np.float32)
+    rp, c, v = _dev_csr(rowptr, col, val, dev)
+    plan = ops.SpmmPlan.build(rp, hub_threshold=24, segment_edges=128)
+    assert plan.n_multi == 3 and plan.combine is not None
+    xd, addd = torch.from_numpy(x).to(dev), torch.from_numpy(add).to(dev)
+    y64 = cp.spmm_f64(rowptr, col, val, x, "sum") * 0.5 + 2.0 * add
+    ref = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", 0.5, addd, 2.0, plan=plan.without_combine())
+    for _ in range(5):
+        out = torch.full((n_rows, width), float("nan"), device=dev)
+        y = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", 0.5, addd, 2.0, out=out, plan=plan)
+        tol = 1e-4 + 1e-4 * np.abs(y64) + 1e-6 * np.sqrt(3000)
+        assert np.all(np.abs(y.cpu().numpy() - y64) <= tol)
+        assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+        assert int(torch.count_nonzero(plan.combine.view(torch.int32))) == 0
+    from torch_geometric_autoscale import _lib
+    _lib.check_device_errors()
 
 
 def test_spmm_empty_and_degenerate(ops, dev):
