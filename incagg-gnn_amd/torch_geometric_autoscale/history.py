@@ -31,8 +31,13 @@ class History(torch.nn.Module):
         pin_memory = on_host and torch.cuda.is_available()
         # Deliberately a plain attribute, not a buffer: it never enters a state_dict
         # and `.to()` does not move it (history.py:18,28-31).
-        self.emb = torch.empty(num_embeddings, embedding_dim, device=device,
-                               pin_memory=pin_memory)
+        # and, in HBM, with the row pitch the aggregation kernels want for matrices they gather
+        # from (ops.row_pitch): `emb` is then a [N, dim] view of a slightly wider allocation.
+        if on_host:
+            self.emb = torch.empty(num_embeddings, embedding_dim, device=device,
+                                   pin_memory=pin_memory)
+        else:
+            self.emb = ops.rows_empty(num_embeddings, embedding_dim, device)
         self._device = torch.device("cpu")
         self.reset_parameters()
 

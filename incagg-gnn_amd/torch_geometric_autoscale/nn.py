@@ -15,8 +15,18 @@ import torch
 from torch import Tensor
 from torch.nn import Linear, Parameter
 
+from . import ops
 from .aggregate import spmm
 from .sparse import SparseTensor
+
+
+def _mm_rows(a: Tensor, b: Tensor) -> Tensor:
+    """``a @ b`` written into a matrix with the row pitch the aggregation kernels want for
+    their sources (ops.row_pitch): layer outputs and input gradients are what the next
+    aggregation gathers from."""
+    if not a.is_cuda or a.dim() != 2:
+        return a @ b
+    return torch.mm(a, b, out=ops.rows_empty(a.size(0), b.size(1), a.device, a.dtype))
 
 
 def _slab_count(rows: int) -> int:
@@ -76,14 +86,14 @@ class _RowsLinear(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         if bias is None:
-            return x @ weight.t()
+            return _mm_rows(x, weight.t())
         return torch.addmm(bias, x, weight.t())
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dx = _mm_rows(dy, weight) if ctx.needs_input_grad[0] else None
         dw = _tn_product(dy, x) if ctx.needs_input_grad[1] else None
         db = _column_sums(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
@@ -102,7 +112,9 @@ class _EmbedRelu(torch.autograd.Function):
         if bias is not None and x.is_cuda:
             # bias and relu ride in the GEMM epilogue (hipBLASLt): 104 us instead of 145 us for
             # the 128k x 100 -> 256 embedding of a products batch
-            h = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+            h = torch._addmm_activation(bias, x, weight.t(), use_gelu=False,
+                                        out=ops.rows_empty(x.size(0), weight.size(0), x.device,
+                                                           x.dtype))
         else:
             h = (x @ weight.t() if bias is None else torch.addmm(bias, x, weight.t())).relu_()
         ctx.save_for_backward(x, weight, h)
@@ -150,15 +162,15 @@ class _TwoTermUpdate(torch.autograd.Function):
             ctx.mark_dirty(term)
             return term.addmm_(h, w1)
         if x0 is None:
-            return h @ w1
-        return torch.addmm(x0 @ w2, h, w1)
+            return _mm_rows(h, w1)
+        return _mm_rows(x0, w2).addmm_(h, w1)
 
     @staticmethod
     def backward(ctx, dy):
         h, w1, x0, w2 = ctx.saved_tensors
         if dy.stride(-1) != 1:
             dy = dy.contiguous()
-        dh = dy @ w1.t() if ctx.needs_input_grad[0] else None
+        dh = _mm_rows(dy, w1.t()) if ctx.needs_input_grad[0] else None
         dw1 = _tn_product(h, dy) if ctx.needs_input_grad[1] else None
         dx0 = dw2 = None
         if x0 is not None:
@@ -178,7 +190,8 @@ class _X0Terms(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_0, wcat, n_layers, grad_stack):
-        buf = x_0 @ wcat
+        # (row pitch: the blocks become layer outputs, which the next aggregation gathers from)
+        buf = _mm_rows(x_0, wcat)
         c = wcat.size(1) // n_layers
         ctx.save_for_backward(x_0, wcat)
         ctx.grad_stack, ctx.c = grad_stack, c
