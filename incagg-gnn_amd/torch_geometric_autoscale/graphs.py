@@ -1,27 +1,27 @@
 """HIP-graph capture of whole training steps.
 
-A history-based training step is ~180 kernel launches (aggregations, History pushes, GEMMs,
+A history-based training step is ~110 kernel launches (aggregations, History pushes, GEMMs,
 element-wise glue, the optimizer) issued from Python; on MI355X the launches of one step take
-the host about as long as the GPU needs to run them.  A step over a given partition batch is
-the same launch sequence every epoch -- same shapes, same addresses once its inputs are kept
-in static tensors -- so it is recorded once into a HIP graph and replayed with a single call.
+the host longer than the GPU needs to run them.  A step over a given partition batch is the
+same launch sequence every epoch -- same shapes, same addresses once its inputs are kept in
+static tensors -- so it is recorded once into a HIP graph and replayed with a single call.
 
 All graphs of a :class:`StepGraphs` share one memory pool and one capture stream (they are
-replayed one after the other, never concurrently).  The aggregation library needs its
-per-stream slice queue to exist before a stream is captured; :meth:`StepGraphs.warm` runs the
-step eagerly on the capture stream first, which creates it (and every lazily built per-batch
-structure: transposed CSR, row orders, in-place column ids).
+replayed one after the other, never concurrently).  The aggregation and History-row entry
+points allocate nothing and keep no state of their own between launches, so they record as plain
+kernel nodes; :meth:`StepGraphs.warm` runs the step eagerly on the capture stream first, which
+builds every lazily built per-batch structure (transposed CSR, work plans, in-place column ids)
+outside the recording.  Tensors a recorded step reads -- batch arrays, plans and their combine
+buffers, History tables, parameters -- must stay alive and keep their addresses.
 
-Known limitation (observed on ROCm 7.0 / torch 2.10, cause not established): replaying recorded
-steps AFTER other work had been issued eagerly on the device since the recording -- a refresh
-sweep between two epochs of replays -- ended in an illegal memory access, while the same
-graphs replay indefinitely when nothing eager runs in between (warm everything, record
-everything, then only replay: what ``bench.py`` does), and recording / replaying interleaved
-with eager *training steps* is fine too.  Until that is understood, loops that alternate
-training epochs with eager sweeps (``train.run``) issue their steps eagerly.  (The slice
-kernels of the aggregation check every queue entry against the row count and row length of the
-call they belong to and report a foreign entry through the device error flag instead of
-following it, so a stale queue cannot be what turns into a memory fault.)
+Known limitation (observed on ROCm 7.0 / torch 2.10 with an earlier build of the library; cause
+not established, and not re-tested since): replaying recorded steps AFTER other work had been
+issued eagerly on the device since the recording -- a refresh sweep between two epochs of replays
+-- ended in an illegal memory access, while the same graphs replay indefinitely when nothing
+eager runs in between (warm everything, record everything, then only replay: what ``bench.py``
+does), and recording / replaying interleaved with eager *training steps* is fine too.  Loops
+that alternate training epochs with eager sweeps (``train.run``) therefore issue their steps
+eagerly.
 """
 from typing import Callable, Dict, Hashable
 

@@ -45,14 +45,18 @@ def timeit(fn, n=REPS):
     return s.elapsed_time(e) / n * 1e3
 
 
-x = torch.randn(M, F, device=dev)
-xb = x[:B].contiguous()
-halo = x[B:].contiguous()
-table = torch.randn(N, F, device=dev)
+def rnd(rows):   # row pitch as the package allocates gathered matrices (ops.row_pitch)
+    return ops.rows_empty(rows, F, dev).normal_()
+
+
+x = rnd(M)
+xb = rnd(B).copy_(x[:B])
+halo = rnd(M - B).copy_(x[B:])
+table = rnd(N)
 n_id = sub.n_id.to(dev)
 cip = adj.col_in_place(n_id[B:], B)
 trp, tc, tv = adj.device_csr_t("sum")
-dy = torch.randn(B, F, device=dev)
+dy = rnd(B)
 
 shapes = {
     "fwd [B,M] one source": lambda plan: ops.spmm_csr(rp, c, v, x, M, plan=plan),
@@ -102,7 +106,7 @@ print("done", flush=True)
 # ---- out-of-batch rows HBM-cold (as inside a training step: every layer reads another table),
 # with the edges of every row in storage order vs in-batch columns first
 if os.environ.get("COLD", "1") == "1":
-    tables = [torch.randn(N, F, device=dev) for _ in range(8)]
+    tables = [rnd(N) for _ in range(8)]
     row = torch.repeat_interleave(torch.arange(B, device=dev), deg.to(torch.int64))
     key = row * 2 + (c >= B).to(torch.int64)
     perm = torch.argsort(key, stable=True)

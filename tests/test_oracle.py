@@ -73,6 +73,35 @@ def test_aggregation_oracle_against_naive_loops(reduce, width):
     assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs))
 
 
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_aggregation_oracle_against_torch_sparse_csr(reduce):
+    """The CPU path the reference's arithmetic reduces to without torch-sparse: a
+    ``torch.sparse_csr_tensor @ x`` (medium graph with long rows and empty rows), forward and
+    transposed, against the C restatement."""
+    import torch
+    rng = np.random.default_rng(21)
+    n_rows, n_cols, width = 3000, 5000, 96
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, 12, hubs={5: 2500, 77: 900},
+                                  empty_rows=(0, 1234, 2999))
+    x = rng.standard_normal((n_cols, width)).astype(np.float32)
+    v = val if reduce == "sum" else None
+    a = torch.sparse_csr_tensor(torch.from_numpy(rowptr), torch.from_numpy(col),
+                                torch.from_numpy(val if v is not None else
+                                                 np.ones(col.size, np.float32)),
+                                size=(n_rows, n_cols))
+    want = (a @ torch.from_numpy(x)).numpy()
+    if reduce == "mean":
+        want = want / np.maximum(np.diff(rowptr), 1)[:, None]
+    got = cp.spmm(rowptr, col, v, x, reduce)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    # transposed: A^T dY as the backward pass computes it
+    dy = rng.standard_normal((n_rows, width)).astype(np.float32)
+    want_t = (a.to_dense().t() @ torch.from_numpy(dy)).numpy()
+    if reduce == "sum":
+        np.testing.assert_allclose(cp.spmm_t(rowptr, col, v, dy, n_cols, reduce), want_t,
+                                   rtol=1e-4, atol=1e-4)
+
+
 def test_incagg_oracle_is_the_three_step_formula():
     rng = np.random.default_rng(4)
     b, w = 50, 8
