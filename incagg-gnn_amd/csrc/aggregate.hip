@@ -352,6 +352,23 @@ __device__ __forceinline__ f4 shfl_xor4(f4 v, int m) {
   return r;
 }
 
+// 16 bytes of a row at a 4-byte-aligned address.  Rows start 16-byte aligned and the pieces of a
+// row are 16 bytes apart, except the LAST piece of a row whose width is not a multiple of 4: that
+// piece is moved back so that it ends with the row (it overlaps its neighbour, see `skip` in the
+// kernel), which keeps every lane on one 16-byte access and nothing outside the row touched.
+// ODD (the width is not a multiple of 4) selects the 4-byte-aligned access type.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool ODD>
+__device__ __forceinline__ f4 ld4(const float *p) {
+  if constexpr (ODD) return *reinterpret_cast<const f4u *>(p);
+  else return *reinterpret_cast<const f4 *>(p);
+}
+template <bool ODD>
+__device__ __forceinline__ void st4(float *p, f4 v) {
+  if constexpr (ODD) *reinterpret_cast<f4u *>(p) = v;
+  else *reinterpret_cast<f4 *>(p) = v;
+}
+
 // Column ids / weights of the 64-edge window starting at e0, one coalesced load each.
 // Lane 8 g + j holds window edge 8 j + g: round j of lane group g (see gather_rounds).
 // The 64 addresses still fall into the same two cache lines, so the load stays coalesced.
@@ -385,7 +402,7 @@ __device__ __forceinline__ int group_bcast(int v) {
 // the row gathers.
 // WIDE: row offsets need 64 bits or the source is split in two matrices; otherwise a
 // 32-bit byte offset per lane on top of a scalar base is enough.
-template <bool INCAGG, bool WIDE, int R0, int N>
+template <bool INCAGG, bool WIDE, bool ODD, int R0, int N>
 __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float my_w, int coloff,
                                               f4 &acc) {
   int c[N];
@@ -410,16 +427,17 @@ __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float
     if constexpr (WIDE) {
       const float *xr = c[r] < a.split ? a.x + (size_t)c[r] * a.ldx
                                        : a.x2 + (size_t)(c[r] - a.split) * a.ldx2;
-      xv[r] = vrelu<4>(ldv<4>(xr + coloff), a.relu_x && c[r] < a.split);
-      if (INCAGG) mv[r] = ldv<4>(a.m_in + (size_t)c[r] * a.ldin + coloff);
+      xv[r] = vrelu<4>(ld4<ODD>(xr + coloff), a.relu_x && c[r] < a.split);
+      if (INCAGG) mv[r] = ld4<ODD>(a.m_in + (size_t)c[r] * a.ldin + coloff);
     } else {
       // byte offsets computed in 32 bits: "scalar base + 32-bit lane offset" addressing
       const unsigned off = ((unsigned)c[r] * (unsigned)a.ldx + (unsigned)coloff) * 4u;
-      xv[r] = vrelu<4>(*reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.x) + off),
-                       a.relu_x != 0);
+      xv[r] = vrelu<4>(
+          ld4<ODD>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.x) + off)),
+          a.relu_x != 0);
       if (INCAGG) {
         const unsigned moff = ((unsigned)c[r] * (unsigned)a.ldin + (unsigned)coloff) * 4u;
-        mv[r] = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.m_in) + moff);
+        mv[r] = ld4<ODD>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.m_in) + moff));
       }
     }
   }
@@ -429,22 +447,22 @@ __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float
 
 // `rounds` (wave-uniform, 1..8) rounds of the indices in (my_c, my_w): short windows only
 // pay for the rounds they fill: 1, 2, 4 or 8.
-template <bool INCAGG, bool WIDE>
+template <bool INCAGG, bool WIDE, bool ODD>
 __device__ __forceinline__ void gather_some(const SpmmArgs &a, int my_c, float my_w, int rounds,
                                             int coloff, f4 &acc) {
   if (rounds > 4) {
     if constexpr (INCAGG) {  // two operands per edge: 4 rounds = 8 gathers in flight
-      gather_rounds<INCAGG, WIDE, 0, 4>(a, my_c, my_w, coloff, acc);
-      gather_rounds<INCAGG, WIDE, 4, 4>(a, my_c, my_w, coloff, acc);
+      gather_rounds<INCAGG, WIDE, ODD, 0, 4>(a, my_c, my_w, coloff, acc);
+      gather_rounds<INCAGG, WIDE, ODD, 4, 4>(a, my_c, my_w, coloff, acc);
     } else {
-      gather_rounds<INCAGG, WIDE, 0, 8>(a, my_c, my_w, coloff, acc);
+      gather_rounds<INCAGG, WIDE, ODD, 0, 8>(a, my_c, my_w, coloff, acc);
     }
   } else if (rounds > 2) {
-    gather_rounds<INCAGG, WIDE, 0, 4>(a, my_c, my_w, coloff, acc);
+    gather_rounds<INCAGG, WIDE, ODD, 0, 4>(a, my_c, my_w, coloff, acc);
   } else if (rounds > 1) {
-    gather_rounds<INCAGG, WIDE, 0, 2>(a, my_c, my_w, coloff, acc);
+    gather_rounds<INCAGG, WIDE, ODD, 0, 2>(a, my_c, my_w, coloff, acc);
   } else {
-    gather_rounds<INCAGG, WIDE, 0, 1>(a, my_c, my_w, coloff, acc);
+    gather_rounds<INCAGG, WIDE, ODD, 0, 1>(a, my_c, my_w, coloff, acc);
   }
 }
 
@@ -456,7 +474,7 @@ __device__ __forceinline__ int group_max8(int v) {  // max over the 8 lane group
 }
 
 // (second launch bound: waves per SIMD the register allocation must leave room for)
-template <bool INCAGG, bool WIDE>
+template <bool INCAGG, bool WIDE, bool ODD>
 __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_plan_kernel(
     const SpmmArgs a, int n_slices) {
   __shared__ f4 part[kWavesPerBlock][8];
@@ -467,7 +485,11 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
   const int vb = blockIdx.x / n_slices;
   const int col0 = slice * kSliceFloats + t * 4;
   const bool live = col0 < a.width;
-  const int coloff = live ? col0 : 0;
+  // (width >= 4.)  A row's last piece ends with the row: when the width is not a multiple of 4
+  // its first `skip` floats are also the last floats of the neighbouring lane's piece -- both
+  // lanes compute them from the same inputs in the same order, i.e. bit-identically.
+  const int coloff = live ? min(col0, a.width - 4) : 0;
+  const int skip = live ? col0 - coloff : 0;
 
   if (vb < a.n_items) {
     // ---- one segment of a long row x one slice: wave w takes the windows w, w + 4, ...; in
@@ -483,7 +505,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
       for (; e0 < ee; e0 += kWave * kWavesPerBlock) {
         const int ne0 = e0 + kWave * kWavesPerBlock;
         if (ne0 < ee) load_window(a, ne0, ee, lane, next_c, next_w);
-        gather_some<INCAGG, WIDE>(a, my_c, my_w, (min(kWave, ee - e0) + 7) >> 3, coloff, acc);
+        gather_some<INCAGG, WIDE, ODD>(a, my_c, my_w, (min(kWave, ee - e0) + 7) >> 3, coloff, acc);
         my_c = next_c;
         my_w = next_w;
       }
@@ -512,13 +534,13 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
     const float s = a.scale * (a.mean ? 1.0f / (float)max(deg, 1) : 1.0f);
     f4 out = acc * s;
     if (seg_idx == 0) {
-      if (INCAGG) out += a.scale * ldv<4>(a.m_ag + (size_t)row * a.ldag + coloff);
-      if (a.add) out += a.add_scale * ldv<4>(a.add + (size_t)row * a.ldadd + coloff);
+      if (INCAGG) out += a.scale * ld4<ODD>(a.m_ag + (size_t)row * a.ldag + coloff);
+      if (a.add) out += a.add_scale * ld4<ODD>(a.add + (size_t)row * a.ldadd + coloff);
     }
-    if (a.gate) out = vgate<4>(out, ldv<4>(a.gate + (size_t)row * a.ldgate + coloff));
+    if (a.gate) out = vgate<4>(out, ld4<ODD>(a.gate + (size_t)row * a.ldgate + coloff));
     float *dst = a.y + (size_t)row * a.ldy + coloff;
     if (!multi) {
-      stv<4>(dst, out);
+      st4<ODD>(dst, out);
     } else if (a.comb) {
       // Segments of one row meet in the plan's combine buffer, which is all zero between
       // launches: every segment adds its part, then counts its arrival; the last one to
@@ -528,24 +550,29 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
       // in front of the arrival count without a release fence (which would write the XCD's
       // whole L2 back).
       float *accp = a.comb + (size_t)slot * kCombineSlot + coloff;
-      const float r0 = atomicAdd(accp, out.x), r1 = atomicAdd(accp + 1, out.y);
-      const float r2 = atomicAdd(accp + 2, out.z), r3 = atomicAdd(accp + 3, out.w);
+      // (floats shared with the neighbouring piece are added by that piece only)
+      const float r0 = atomicAdd(accp, skip > 0 ? 0.f : out.x);
+      const float r1 = atomicAdd(accp + 1, skip > 1 ? 0.f : out.y);
+      const float r2 = atomicAdd(accp + 2, skip > 2 ? 0.f : out.z);
+      const float r3 = atomicAdd(accp + 3, out.w);
       asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
       int *cnt = reinterpret_cast<int *>(a.comb + (size_t)slot * kCombineSlot + kCombineWidth) + slice;
       int prev = 0;
       if (t == 0) prev = atomicAdd(cnt, 1);
       prev = rfl(prev);   // (lane 0 is live and active: the first active lane)
       if (prev == (deg + a.seg - 1) / a.seg - 1) {
-        f4 tot;
-        tot.x = atomicExch(accp, 0.f); tot.y = atomicExch(accp + 1, 0.f);
-        tot.z = atomicExch(accp + 2, 0.f); tot.w = atomicExch(accp + 3, 0.f);
+        // (only the floats this piece owns: the shared ones are the neighbouring piece's, which
+        // may sit in another slice with arrivals of its own)
+        if (skip < 1) dst[0] = atomicExch(accp, 0.f);
+        if (skip < 2) dst[1] = atomicExch(accp + 1, 0.f);
+        if (skip < 3) dst[2] = atomicExch(accp + 2, 0.f);
+        dst[3] = atomicExch(accp + 3, 0.f);
         if (t == 0) atomicExch(cnt, 0);
-        stv<4>(dst, tot);
       }
     } else {  // several segments add onto the row, zeroed in front of this launch
-      atomicAdd(dst, out.x);
-      atomicAdd(dst + 1, out.y);
-      atomicAdd(dst + 2, out.z);
+      if (skip < 1) atomicAdd(dst, out.x);
+      if (skip < 2) atomicAdd(dst + 1, out.y);
+      if (skip < 3) atomicAdd(dst + 2, out.z);
       atomicAdd(dst + 3, out.w);
     }
     return;
@@ -593,7 +620,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
   for (int done = 0; done < maxdeg; done += 8) {
     if (done + 8 < maxdeg) load_idx(e + 8, next_c, next_w);
     // (rounds that SOME group still needs: wave-uniform)
-    if (e < re) gather_some<INCAGG, WIDE>(a, my_c, my_w, maxdeg - done, coloff, acc);
+    if (e < re) gather_some<INCAGG, WIDE, ODD>(a, my_c, my_w, maxdeg - done, coloff, acc);
     my_c = next_c;
     my_w = next_w;
     e += 8;
@@ -601,10 +628,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
   if (valid && live) {
     const float s = a.scale * (a.mean ? 1.0f / (float)max(deg, 1) : 1.0f);
     f4 out = acc * s;
-    if (INCAGG) out += a.scale * ldv<4>(a.m_ag + (size_t)row * a.ldag + coloff);
-    if (a.add) out += a.add_scale * ldv<4>(a.add + (size_t)row * a.ldadd + coloff);
-    if (a.gate) out = vgate<4>(out, ldv<4>(a.gate + (size_t)row * a.ldgate + coloff));
-    stv<4>(a.y + (size_t)row * a.ldy + coloff, out);
+    if (INCAGG) out += a.scale * ld4<ODD>(a.m_ag + (size_t)row * a.ldag + coloff);
+    if (a.add) out += a.add_scale * ld4<ODD>(a.add + (size_t)row * a.ldadd + coloff);
+    if (a.gate) out = vgate<4>(out, ld4<ODD>(a.gate + (size_t)row * a.ldgate + coloff));
+    st4<ODD>(a.y + (size_t)row * a.ldy + coloff, out);
   }
 }
 
@@ -736,10 +763,15 @@ static int launch_sliced(SpmmArgs &a, const incagg_spmm_plan *plan, hipStream_t 
   const bool wide = a.x2 != nullptr || (long long)a.n_cols * a.ldx * 4 >= (1ll << 32) ||
                     (INCAGG && (long long)a.n_cols * a.ldin * 4 >= (1ll << 32));
   const dim3 grid((unsigned)(blocks * n_slices)), block(kWave * kWavesPerBlock);
-  if (wide)
-    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, true>), grid, block, 0, stream, a, n_slices);
+  const bool odd = a.width % 4 != 0;
+  if (wide && odd)
+    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, true, true>), grid, block, 0, stream, a, n_slices);
+  else if (wide)
+    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, true, false>), grid, block, 0, stream, a, n_slices);
+  else if (odd)
+    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, false, true>), grid, block, 0, stream, a, n_slices);
   else
-    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, false>), grid, block, 0, stream, a, n_slices);
+    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, false, false>), grid, block, 0, stream, a, n_slices);
   INCAGG_HIP_TRY(hipGetLastError());
   return INCAGG_OK;
 }
@@ -753,8 +785,9 @@ static int dispatch_spmm(SpmmArgs &a, bool vec4, const incagg_spmm_plan *plan,
   // "spmm_variant" tuning key: 0 = whole rows per wave, 1 = feature slices, -1 = slices whenever
   // the rows are 16-byte aligned.  Measured on MI355X, ogbn-products-sized batch, width 256.
   const int mode = tuning().spmm_variant;
-  if (vec4 && mode != 0) return launch_sliced<INCAGG>(a, plan, stream);
-  if (vec4) {
+  // (forced whole rows: widths beyond the whole-row kernel's reach still take the slices)
+  if (vec4 && (mode != 0 || (w % 4 != 0 && w > 256))) return launch_sliced<INCAGG>(a, plan, stream);
+  if (vec4 && w % 4 == 0) {
     if (w <= 256) return launch_rows<4, 1, INCAGG>(a, plan, stream);
     if (w <= 512) return launch_rows<4, 2, INCAGG>(a, plan, stream);
     if (w <= 1024) return launch_rows<4, 4, INCAGG>(a, plan, stream);
@@ -827,7 +860,8 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
   }
   rc = error_flag_address(&a.err);
   if (rc) return rc;
-  const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(x_halo, ld_halo) &&
+  // (widths >= 4 that are not a multiple of 4 qualify too: only the alignment of the rows counts)
+  const bool vec4 = width >= 4 && rows_vec4(x, ldx) && rows_vec4(x_halo, ld_halo) &&
                     rows_vec4(add, ldadd) && rows_vec4(y, ldy) && rows_vec4(a.gate, a.ldgate);
   return dispatch_spmm<false>(a, vec4, plan, static_cast<hipStream_t>(stream));
 }
@@ -857,7 +891,7 @@ extern "C" int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *
   a.nnz = (int)nnz;
   rc = error_flag_address(&a.err);
   if (rc) return rc;
-  const bool vec4 = width % 4 == 0 && rows_vec4(x, ldx) && rows_vec4(m_in, ldin) &&
+  const bool vec4 = width >= 4 && rows_vec4(x, ldx) && rows_vec4(m_in, ldin) &&
                     rows_vec4(m_ag, ldag) && rows_vec4(add, ldadd) && rows_vec4(h, ldh);
   return dispatch_spmm<true>(a, vec4, plan, static_cast<hipStream_t>(stream));
 }

@@ -87,7 +87,10 @@ class _RowsLinear(torch.autograd.Function):
         ctx.has_bias = bias is not None
         if bias is None:
             return _mm_rows(x, weight.t())
-        return torch.addmm(bias, x, weight.t())
+        if not x.is_cuda or x.dim() != 2:
+            return torch.addmm(bias, x, weight.t())
+        return torch.addmm(bias, x, weight.t(),
+                           out=ops.rows_empty(x.size(0), weight.size(0), x.device, x.dtype))
 
     @staticmethod
     def backward(ctx, dy):

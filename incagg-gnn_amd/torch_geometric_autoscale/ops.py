@@ -47,7 +47,11 @@ def row_pitch(width: int) -> int:
     of 128-byte lines (256 floats = 8 lines, worst: a power of two) those addresses share their
     low bits and crowd into a fraction of the L2's channels and sets.  One line of padding makes
     the line count odd: measured on MI355X, products batch at width 256, forward 95.6 -> 81.2 us,
-    transposed window 52.8 -> 44.2 us.  Widths that are not whole lines are left alone."""
+    transposed window 52.8 -> 44.2 us.  Widths that are not a multiple of 4 floats are rounded
+    up to a multiple of 16: rows then start 16-byte aligned, which is what the feature-sliced
+    kernel needs (width 41, same batch: 108 -> 75 us against the whole-row kernel)."""
+    if width >= 8 and width % 4 != 0:
+        width = (width + 15) // 16 * 16
     if width < 64 or width % 32 != 0 or (width // 32) % 2 == 1:
         return width
     return width + 32

@@ -80,15 +80,17 @@ int incagg_check_device_errors(void);
  *     plan the rows are processed in storage order and every row by one wave (or one group of 8
  *     lanes), however long it is: correct, but slow on power-law graphs.
  *   y[n_rows, width] ld = ldy; must not alias x, x_halo or add.
- *   width <= 1024 when every pointer is 16-byte aligned and every ld a multiple
- *   of 4, else width <= 256.
+ *   width <= 1024 when every row starts 16-byte aligned (every pointer 16-byte aligned, every
+ *   ld a multiple of 4; the width itself need not be a multiple of 4), else width <= 256.
  *
  * One launch per call.  Rows cut into several segments are combined with fp32 atomics, in the
  * plan's combine buffer or, without one, on the output row, which a small launch in front then
  * zeroes; every other row is written by exactly one wave with a fixed summation order, i.e.
  * bit-reproducibly.  Two kernels, chosen
  * by alignment: 128-byte feature slices pinned to one XCD each so that every source byte has a
- * single home L2, 8 short rows per wave; or whole rows per wave (any width / alignment).  The
+ * single home L2, 8 short rows per wave (rows that start 16-byte aligned: give matrices of odd
+ * widths such as 41 or 47 a padded pitch, and every gathered matrix a pitch of an odd number of
+ * 128-byte lines); or whole rows per wave (any width / alignment, about 2.5x slower).  The
  * call allocates nothing, keeps no state between calls and may be recorded into a HIP graph.
  */
 typedef struct incagg_spmm_plan {

@@ -49,8 +49,9 @@ def pitched(rows, pitch):
 
 
 print(f"B={B} M={M} E={E} F={F}", flush=True)
-for pad in (0, 32, 64, 96, 160, 8):
-    pitch = F + pad
+PITCHES = [int(v) for v in os.environ.get("PITCHES", "").split(",") if v] or \
+    [F + pad for pad in (0, 32, 64, 96, 160, 8)]
+for pitch in PITCHES:
     tables = [pitched(N, pitch) for _ in range(6)]
     xb = pitched(B, pitch)
     xm = pitched(M, pitch)

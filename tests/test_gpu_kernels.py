@@ -86,6 +86,59 @@ def test_spmm_matches_oracle(ops, dev, width, reduce, variant):
     _lib.check_device_errors()
 
 
+def _pitched(a, dev, pitch, fill=float("nan")):
+    """``a`` on the device as a [rows, width] view of a [rows, pitch] matrix whose other
+    columns hold ``fill``."""
+    buf = torch.full((a.shape[0], pitch), fill, dtype=torch.float32, device=dev)
+    buf[:, :a.shape[1]] = torch.from_numpy(a).to(dev)
+    return buf, buf[:, :a.shape[1]]
+
+
+@pytest.mark.parametrize("width", [41, 47, 3, 6, 9, 33, 35, 129, 1023])
+def test_spmm_odd_widths_on_aligned_rows(ops, dev, width, variant):
+    """Widths that are not a multiple of 4 on rows that start 16-byte aligned (the pitch the
+    package allocates, ops.row_pitch): the feature-sliced kernel moves a row's last, partial
+    piece float by float -- NaNs parked in the padding of every operand never reach a result,
+    the padding of the output is not written, with every epilogue, rows cut into several
+    segments, and the incremental aggregate."""
+    rng = np.random.default_rng(1000 + width)
+    n_rows, n_cols = 200, 200
+    pitch = (width + 15) // 16 * 16 + 16
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, 7, hubs={3: 190, 100: 140},
+                                  empty_rows=(0, 199))
+    x = rng.standard_normal((n_cols, width)).astype(np.float32)
+    add = rng.standard_normal((n_rows, width)).astype(np.float32)
+    gate = rng.standard_normal((n_rows, width)).astype(np.float32)
+    rp, c, v = _dev_csr(rowptr, col, val, dev)
+    plan = _plan(variant, rp)
+    (_, xd), (_, addd), (_, gated) = (_pitched(t, dev, pitch) for t in (x, add, gate))
+    ybuf = torch.full((n_rows, pitch), 7.0, device=dev)
+    y = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", 0.5, addd, 2.0, out=ybuf[:, :width], plan=plan,
+                     relu_x=True, gate=gated)
+    want = (0.5 * cp.spmm_f64(rowptr, col, val, np.maximum(x, 0), "sum") + 2.0 * add) * (gate > 0)
+    _check(y, want)
+    assert bool((ybuf[:, width:] == 7.0).all())
+    # split source + mean
+    xb, xh = x[:120], x[120:]
+    (_, xbd), (_, xhd) = _pitched(xb, dev, pitch), _pitched(xh, dev, pitch + 16)
+    y = ops.spmm_csr(rp, c, None, xbd, n_cols, "mean", x_halo=xhd, out=ybuf[:, :width], plan=plan)
+    _check(y, cp.spmm_f64(rowptr, col, None, x, "mean"))
+    assert bool((ybuf[:, width:] == 7.0).all())
+    # incremental aggregate on the square part
+    rowptr2, col2, val2 = random_csr(rng, n_rows, n_rows, 7, hubs={3: 190, 100: 140})
+    m_in = rng.standard_normal((n_rows, width)).astype(np.float32)
+    m_ag = rng.standard_normal((n_rows, width)).astype(np.float32)
+    rp2, c2, v2 = _dev_csr(rowptr2, col2, val2, dev)
+    (_, mind), (_, magd) = _pitched(m_in, dev, pitch), _pitched(m_ag, dev, pitch)
+    h = ops.spmm_csr_incagg(rp2, c2, v2, xd, mind, magd, "sum", out=ybuf[:, :width],
+                            plan=_plan(variant, rp2))
+    _check(h, cp.spmm_f64(rowptr2, col2, val2, (x[:n_rows].astype(np.float64) - m_in)
+                          .astype(np.float32), "sum") + m_ag)
+    assert bool((ybuf[:, width:] == 7.0).all())
+    from torch_geometric_autoscale import _lib
+    _lib.check_device_errors()
+
+
 def test_spmm_epilogue_and_strides(ops, dev, variant):
     rng = np.random.default_rng(3)
     n_rows, n_cols, width = 257, 400, 256
