@@ -68,6 +68,17 @@ __device__ __forceinline__ f4 vrelu<4>(f4 v, bool on) {
   r.z = on ? fmaxf(v.z, 0.f) : v.z; r.w = on ? fmaxf(v.w, 0.f) : v.w;
   return r;
 }
+// max(0, v) as ONE integer max per float: a float with its sign bit set is a negative int, so
+// max(bits, 0) gives +0.0 for everything negative and keeps everything else (NaNs with a clear
+// sign bit included); with the lower bound INT_MIN instead of 0 the value passes unchanged.
+__device__ __forceinline__ float relu_lb(float v, int lb) {
+  return __int_as_float(max(__float_as_int(v), lb));
+}
+__device__ __forceinline__ f4 relu_lb4(f4 v, int lb) {
+  f4 r;
+  r.x = relu_lb(v.x, lb); r.y = relu_lb(v.y, lb); r.z = relu_lb(v.z, lb); r.w = relu_lb(v.w, lb);
+  return r;
+}
 // v where g > 0, else 0, per component
 template <int VEC>
 __device__ __forceinline__ typename VT<VEC>::type vgate(typename VT<VEC>::type v,
@@ -91,6 +102,7 @@ struct SpmmArgs {
   const float *x2;  // source rows [split, n_cols) live here (row c at x2 + (c - split) * ldx2)
   long long ldx2;
   int split;
+  unsigned ldb1, ldb2;  // ldx, ldx2 in bytes
   const float *m_in;
   long long ldin;
   const float *m_ag;
@@ -402,7 +414,7 @@ __device__ __forceinline__ int group_bcast(int v) {
 // the row gathers.
 // WIDE: row offsets need 64 bits or the source is split in two matrices; otherwise a
 // 32-bit byte offset per lane on top of a scalar base is enough.
-template <bool INCAGG, bool WIDE, bool ODD, int R0, int N>
+template <bool INCAGG, int WIDE, bool ODD, int R0, int N>
 __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float my_w, int coloff,
                                               f4 &acc) {
   int c[N];
@@ -424,22 +436,35 @@ __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float
   }
 #pragma unroll
   for (int r = 0; r < N; r++) {
-    if constexpr (WIDE) {
-      const float *xr = c[r] < a.split ? a.x + (size_t)c[r] * a.ldx
-                                       : a.x2 + (size_t)(c[r] - a.split) * a.ldx2;
-      xv[r] = vrelu<4>(ld4<ODD>(xr + coloff), a.relu_x && c[r] < a.split);
+    if constexpr (WIDE != 0) {
+      // two source matrices (or one beyond 4 GiB), branch-free: row id, pitch and base are
+      // selected per lane, then ONE multiply-add -- a 64-bit one in general (WIDE == 1); when
+      // row ids and pitches fit 24 bits and each matrix 4 GiB (WIDE == 2) a full-rate 24-bit
+      // one, which is what a products-sized History table read in place needs
+      const bool second = c[r] >= a.split;
+      const unsigned row = second ? (unsigned)(c[r] - a.split) : (unsigned)c[r];
+      const unsigned ldb = second ? a.ldb2 : a.ldb1;
+      const char *base = second ? reinterpret_cast<const char *>(a.x2)
+                                : reinterpret_cast<const char *>(a.x);
+      unsigned long long off;
+      if constexpr (WIDE == 2) off = __umul24(row, ldb) + (unsigned)coloff * 4u;
+      else off = (unsigned long long)row * ldb + (unsigned)coloff * 4u;
+      xv[r] = ld4<ODD>(reinterpret_cast<const float *>(base + off));
       if (INCAGG) mv[r] = ld4<ODD>(a.m_in + (size_t)c[r] * a.ldin + coloff);
     } else {
       // byte offsets computed in 32 bits: "scalar base + 32-bit lane offset" addressing
       const unsigned off = ((unsigned)c[r] * (unsigned)a.ldx + (unsigned)coloff) * 4u;
-      xv[r] = vrelu<4>(
-          ld4<ODD>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.x) + off)),
-          a.relu_x != 0);
+      xv[r] = ld4<ODD>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.x) + off));
       if (INCAGG) {
         const unsigned moff = ((unsigned)c[r] * (unsigned)a.ldin + (unsigned)coloff) * 4u;
         mv[r] = ld4<ODD>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.m_in) + moff));
       }
     }
+  }
+  if (a.relu_x) {  // (kernel argument: a scalar branch, nothing on the other path)
+#pragma unroll
+    for (int r = 0; r < N; r++)  // rows of the second source matrix are taken as they are
+      xv[r] = relu_lb4(xv[r], WIDE && c[r] >= a.split ? INT_MIN : 0);
   }
 #pragma unroll
   for (int r = 0; r < N; r++) acc += w[r] * (INCAGG ? xv[r] - mv[r] : xv[r]);
@@ -447,7 +472,7 @@ __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float
 
 // `rounds` (wave-uniform, 1..8) rounds of the indices in (my_c, my_w): short windows only
 // pay for the rounds they fill: 1, 2, 4 or 8.
-template <bool INCAGG, bool WIDE, bool ODD>
+template <bool INCAGG, int WIDE, bool ODD>
 __device__ __forceinline__ void gather_some(const SpmmArgs &a, int my_c, float my_w, int rounds,
                                             int coloff, f4 &acc) {
   if (rounds > 4) {
@@ -474,7 +499,7 @@ __device__ __forceinline__ int group_max8(int v) {  // max over the 8 lane group
 }
 
 // (second launch bound: waves per SIMD the register allocation must leave room for)
-template <bool INCAGG, bool WIDE, bool ODD>
+template <bool INCAGG, int WIDE, bool ODD>
 __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_plan_kernel(
     const SpmmArgs a, int n_slices) {
   __shared__ f4 part[kWavesPerBlock][8];
@@ -679,6 +704,7 @@ struct Tuning {
   int spmm_variant = env_int("INCAGG_SPMM_VARIANT", -1);  // -1 by shape, 0 whole rows, 1 slices
   int hub_threshold = env_int("INCAGG_HUB_THRESHOLD", 128);
   int segment_edges = env_int("INCAGG_SEGMENT_EDGES", 4096);
+  int wide_addressing = env_int("INCAGG_WIDE_ADDRESSING", -1);  // 1: never the 24-bit form
 };
 static Tuning &tuning() {
   static Tuning t;
@@ -763,15 +789,24 @@ static int launch_sliced(SpmmArgs &a, const incagg_spmm_plan *plan, hipStream_t 
   const bool wide = a.x2 != nullptr || (long long)a.n_cols * a.ldx * 4 >= (1ll << 32) ||
                     (INCAGG && (long long)a.n_cols * a.ldin * 4 >= (1ll << 32));
   const dim3 grid((unsigned)(blocks * n_slices)), block(kWave * kWavesPerBlock);
+  INCAGG_REQUIRE(a.ldx * 4 < (1ll << 32) && a.ldx2 * 4 < (1ll << 32), "row pitch beyond 4 GiB");
+  a.ldb1 = (unsigned)(a.ldx * 4);
+  a.ldb2 = (unsigned)(a.ldx2 * 4);
+  // 24-bit multiply-add addressing: row ids and pitches below 2^24, each matrix below 4 GiB
+  const long long rows2 = a.x2 ? (long long)a.n_cols - a.split : 0;
+  const bool fast24 = wide && !INCAGG && tuning().wide_addressing != 1 && a.n_cols < (1 << 24) && a.ldb1 < (1u << 24) &&
+                      a.ldb2 < (1u << 24) && (long long)a.split * a.ldb1 < (1ll << 32) &&
+                      rows2 * a.ldb2 < (1ll << 32);
   const bool odd = a.width % 4 != 0;
-  if (wide && odd)
-    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, true, true>), grid, block, 0, stream, a, n_slices);
-  else if (wide)
-    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, true, false>), grid, block, 0, stream, a, n_slices);
-  else if (odd)
-    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, false, true>), grid, block, 0, stream, a, n_slices);
-  else
-    hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, false, false>), grid, block, 0, stream, a, n_slices);
+#define INCAGG_LAUNCH_PLAN(W, O) \
+  hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, W, O>), grid, block, 0, stream, a, n_slices)
+  if (fast24 && odd) INCAGG_LAUNCH_PLAN(2, true);
+  else if (fast24) INCAGG_LAUNCH_PLAN(2, false);
+  else if (wide && odd) INCAGG_LAUNCH_PLAN(1, true);
+  else if (wide) INCAGG_LAUNCH_PLAN(1, false);
+  else if (odd) INCAGG_LAUNCH_PLAN(0, true);
+  else INCAGG_LAUNCH_PLAN(0, false);
+#undef INCAGG_LAUNCH_PLAN
   INCAGG_HIP_TRY(hipGetLastError());
   return INCAGG_OK;
 }
@@ -903,6 +938,7 @@ extern "C" int incagg_set_tuning(const char *key, int value) {
   if (k == "spmm_variant") t.spmm_variant = value;
   else if (k == "hub_threshold") t.hub_threshold = value;
   else if (k == "segment_edges") t.segment_edges = value;
+  else if (k == "wide_addressing") t.wide_addressing = value;
   else return fail(INCAGG_E_INVALID, "unknown tuning key '%s'", key);
   return INCAGG_OK;
 }

@@ -205,7 +205,8 @@ int incagg_spmm_plan_device_static(const int32_t *rowptr, int64_t n_rows, int32_
  * Launch tuning of the aggregation (no counterpart in the reference; for benchmarks and
  * tests).  Keys: "spmm_variant" (-1 feature slices whenever the rows are 16-byte aligned, 0
  * always whole rows per wave, 1 as -1), "hub_threshold", "segment_edges" (defaults of the plan
- * builders).  Not thread-safe against concurrent aggregation calls.
+ * builders), "wide_addressing" (1: split-source launches always use 64-bit row offsets, -1: the
+ * 24-bit multiply-add form whenever row ids and pitches allow).  Not thread-safe against concurrent aggregation calls.
  */
 int incagg_set_tuning(const char *key, int value);
 

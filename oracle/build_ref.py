@@ -30,8 +30,11 @@ def reference_available() -> bool:
 
 
 def build(force: bool = False) -> str:
-    """Compile the reference relabel sources; returns the path of the .so."""
+    """Compile the reference relabel sources; returns the path of the .so.  Where the
+    reference tree is absent (the GPU box) an object built earlier is used as it is."""
     if not reference_available():
+        if os.path.isfile(OUT_SO):
+            return OUT_SO
         raise FileNotFoundError(f"reference sources not found under {REF_ROOT}")
     srcs = [os.path.join(REF_ROOT, "csrc", "relabel.cpp"),
             os.path.join(REF_ROOT, "csrc", "cpu", "relabel_cpu.cpp")]

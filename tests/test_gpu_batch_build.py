@@ -214,3 +214,49 @@ def test_device_partition_batch_drives_the_model_like_the_host_batch(ops, dev):
     assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)
     for a, b in zip(*grads):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+import os  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(_ROOT, "oracle", "_ref", "ref_relabel.so")),
+                    reason="reference build not present in this tree")
+def test_device_relabel_matches_live_reference(ops, dev, tmp_path):
+    """The device batch builder against the reference's own relabel operators (compiled from
+    the reference's sources by oracle/build_ref.py; the built object travels with the tree) on
+    seeds no committed fixture holds.  The reference runs in a subprocess on the CPU: it
+    registers the same operator names as the product."""
+    import torch_geometric_autoscale as tga
+    adj, ptr = tga.synthetic_graph(30000, 30000 * 14, 12, seed=23)
+    rowptr, col, _ = adj.csr()
+    val = torch.rand(col.numel(), generator=torch.Generator().manual_seed(5))
+    idx = torch.cat([torch.arange(int(ptr[1]), int(ptr[2])), torch.arange(int(ptr[7]), int(ptr[9]))])
+    inp, outp = tmp_path / "in.npz", tmp_path / "out.npz"
+    np.savez(inp, rowptr=rowptr.numpy(), col=col.numpy(), val=val.numpy(), idx=idx.numpy())
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {_ROOT!r})
+from oracle import build_ref
+one_hop, within = build_ref.load()
+d = np.load({str(inp)!r})
+t = lambda k: torch.from_numpy(d[k])
+out = {{}}
+for name, fn in (("one_hop", one_hop), ("within", within)):
+    rp, c, v, nid = fn(t("rowptr"), t("col"), t("val"), t("idx"), True)
+    for k, a in zip(("rp", "c", "v", "nid"), (rp, c, v, nid)):
+        out[f"{{name}}_{{k}}"] = a.numpy()
+np.savez({str(outp)!r}, **out)
+"""
+    subprocess.check_call([sys.executable, "-c", code])
+    ref = np.load(outp)
+    for name, within in (("one_hop", False), ("within", True)):
+        rp, c, v, nid, _ = ops.relabel_one_hop_device(rowptr.to(dev), col.to(dev), val.to(dev),
+                                                      idx.to(dev), within)
+        assert np.array_equal(rp.cpu().numpy().astype(np.int64), ref[f"{name}_rp"]), name
+        assert np.array_equal(c.cpu().numpy().astype(np.int64), ref[f"{name}_c"]), name
+        assert np.array_equal(nid.cpu().numpy(), ref[f"{name}_nid"]), name
+        assert np.array_equal(v.cpu().numpy(), ref[f"{name}_v"]), name

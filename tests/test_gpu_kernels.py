@@ -436,9 +436,19 @@ def _straddling_batch(rng, b, m, hubs):
     return rowptr, col, val
 
 
+@pytest.fixture(params=["offsets24", "offsets64"])
+def addressing(request):
+    """Split-source launches compute row offsets with a 24-bit multiply-add when row ids and
+    pitches allow it (the default) or in 64 bits (forced here)."""
+    from torch_geometric_autoscale import _lib
+    _lib.set_tuning("wide_addressing", 1 if request.param == "offsets64" else -1)
+    yield request.param
+    _lib.set_tuning("wide_addressing", -1)
+
+
 @pytest.mark.parametrize("width", [256, 128, 41])
 @pytest.mark.parametrize("form", ["pulled", "table"])
-def test_spmm_split_source_matches_oracle(ops, dev, width, form, variant):
+def test_spmm_split_source_matches_oracle(ops, dev, width, form, variant, addressing):
     """The aggregation as the push/pull step launches it: source rows < B from the fresh batch
     matrix, the rest either from a pulled matrix or in place from a whole History table
     through rewritten column ids (B + global id); hub rows (> 128 and > 1 024 edges) on both
