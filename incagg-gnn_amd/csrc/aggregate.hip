@@ -97,6 +97,7 @@ struct SpmmArgs {
   const int *rowptr;
   const int *col;
   const float *val;
+  const int2 *edges;  // optional: (col[e], bits of val[e]) side by side, one 8-byte load per edge
   const float *x;
   long long ldx;
   const float *x2;  // source rows [split, n_cols) live here (row c at x2 + (c - split) * ldx2)
@@ -390,8 +391,14 @@ __device__ __forceinline__ void load_window(const SpmmArgs &a, int e0, int re, i
                                             float &w) {
   const int slot = e0 + 8 * (lane & 7) + (lane >> 3);
   const int e = min(slot, re - 1);
-  c = a.col[e];
-  w = a.val ? a.val[e] : 1.0f;
+  if (a.edges) {  // (kernel argument: a scalar branch)
+    const int2 cw = a.edges[e];
+    c = cw.x;
+    w = __int_as_float(cw.y);
+  } else {
+    c = a.col[e];
+    w = a.val ? a.val[e] : 1.0f;
+  }
   if (slot >= re) w = 0.f;
   if ((unsigned)c >= (unsigned)a.n_cols) {  // never fault on a bad id
     *a.err = 1;
@@ -627,8 +634,14 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
     if (e0 < re) {
       const int slot = e0 + t;
       const int e = min(slot, re - 1);
-      c = a.col[e];
-      w = a.val ? a.val[e] : 1.0f;
+      if (a.edges) {
+        const int2 cw = a.edges[e];
+        c = cw.x;
+        w = __int_as_float(cw.y);
+      } else {
+        c = a.col[e];
+        w = a.val ? a.val[e] : 1.0f;
+      }
       if (slot >= re) w = 0.f;
       if ((unsigned)c >= (unsigned)a.n_cols) {  // never fault on a bad id
         *a.err = 1;
@@ -743,6 +756,8 @@ static int bind_plan(SpmmArgs &a, const incagg_spmm_plan *plan) {
   a.seg = plan->segment_edges;
   a.multi_rows = plan->multi_rows;
   a.n_multi = (int)plan->n_multi;
+  a.edges = reinterpret_cast<const int2 *>(plan->edges);
+  INCAGG_REQUIRE(!a.edges || (reinterpret_cast<uintptr_t>(a.edges) & 7) == 0, "plan edges not 8-byte aligned");
   INCAGG_REQUIRE(plan->combine == nullptr || plan->combine_floats >= 0, "negative combine size");
   return INCAGG_OK;
 }

@@ -74,7 +74,8 @@ class SpmmPlanStruct(_c.Structure):
     """``incagg_spmm_plan`` of include/incagg_gnn.h."""
     _fields_ = [("order", _vp), ("items", _vp), ("multi_rows", _vp), ("n_rows", _i64),
                 ("n_hub", _i64), ("n_items", _i64), ("n_multi", _i64), ("hub_threshold", _i32),
-                ("segment_edges", _i32), ("combine", _vp), ("combine_floats", _i64)]
+                ("segment_edges", _i32), ("combine", _vp), ("combine_floats", _i64),
+                ("edges", _vp)]
 
 
 COMBINE_SLOT_FLOATS = 1056      # INCAGG_SPMM_COMBINE_SLOT_FLOATS

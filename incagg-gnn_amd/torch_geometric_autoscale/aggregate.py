@@ -37,8 +37,11 @@ class _SpMM(torch.autograd.Function):
             # out-of-batch column c reads row halo_ids[c - B] of the table x_halo in place
             col = adj.col_in_place(halo_ids, x.size(0))
             n_cols = x.size(0) + x_halo.size(0)
+            plan = adj.plan_edges_in_place(halo_ids, x.size(0))
+        else:
+            plan = adj.plan_edges()
         y = ops.spmm_csr(rowptr, col, val, x, n_cols, reduce, scale, add, add_scale,
-                         x_halo=x_halo, plan=adj.plan(), relu_x=relu_x)
+                         x_halo=x_halo, plan=plan, relu_x=relu_x)
         # relu_x: x holds pre-activations and this call consumes relu(x); gate_grad: x IS the
         # output of a relu whose backward the caller leaves to this call.  Either way the
         # gradient that leaves here is already zeroed where x <= 0.
@@ -84,7 +87,7 @@ class _IncAgg(torch.autograd.Function):
     def forward(ctx, x, add, m_in, m_ag, adj, reduce, scale, add_scale):
         rowptr, col, val = adj.device_csr()
         h = ops.spmm_csr_incagg(rowptr, col, val, x, m_in, m_ag, reduce, scale, add, add_scale,
-                                plan=adj.plan())
+                                plan=adj.plan_edges())
         ctx.adj, ctx.reduce, ctx.scale, ctx.add_scale = adj, reduce, scale, add_scale
         ctx.x_rows = x.size(0)
         ctx.has_add = add is not None

@@ -94,6 +94,7 @@ class SpmmPlan:
         self.n_rows = int(order.numel())
         self.n_hub, self.n_items, self.n_multi = int(n_hub), int(n_items), int(n_multi)
         self.hub_threshold, self.segment_edges = int(hub_threshold), int(segment_edges)
+        self.edges = None      # packed (col, val) pairs of the calls it is used with
         self.combine = None
         if order.is_cuda and self.n_multi > 0:
             self.combine = torch.zeros(self.n_multi * _lib.COMBINE_SLOT_FLOATS,
@@ -118,14 +119,27 @@ class SpmmPlan:
             self._struct = _lib.SpmmPlanStruct(
                 _ptr(self.order), _ptr(self.items), _ptr(self.multi_rows), self.n_rows,
                 self.n_hub, self.n_items, self.n_multi, self.hub_threshold, self.segment_edges,
-                _ptr(self.combine), 0 if self.combine is None else self.combine.numel())
+                _ptr(self.combine), 0 if self.combine is None else self.combine.numel(),
+                _ptr(self.edges))
         return self._struct
+
+    def with_edges(self, edges: Optional[Tensor]) -> "SpmmPlan":
+        """The same plan (same arrays, same combine buffer) for calls whose edge list is also
+        available packed (:func:`pack_edges` of the call's ``col`` / ``val``)."""
+        twin = SpmmPlan.__new__(SpmmPlan)
+        twin.__dict__.update(self.__dict__)
+        twin.edges, twin._struct = edges, None
+        if edges is not None and (edges.dtype != torch.int32 or edges.dim() != 2
+                                  or edges.size(1) != 2 or not edges.is_contiguous()
+                                  or edges.device != self.order.device):
+            raise ValueError("edges must be a contiguous [nnz, 2] int32 tensor on the plan's device")
+        return twin
 
     def without_combine(self) -> "SpmmPlan":
         """The same plan (same arrays) without the combine buffer."""
         twin = SpmmPlan(self.order, self.items, self.multi_rows, self.n_hub, self.n_items,
                         self.n_multi, self.hub_threshold, self.segment_edges)
-        twin.combine = None
+        twin.combine, twin.edges = None, self.edges
         return twin
 
     @staticmethod
@@ -168,6 +182,18 @@ class SpmmPlan:
                         n_hub, n_items, n_multi, thr, seg)
 
 
+def pack_edges(col32: Tensor, val: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """``[nnz, 2]`` int32: ``(col[e], bit pattern of val[e])`` (of 1.0 without values)."""
+    if out is None:
+        out = torch.empty((col32.numel(), 2), dtype=torch.int32, device=col32.device)
+    out[:, 0] = col32
+    if val is None:
+        out[:, 1] = 0x3F800000
+    else:
+        out[:, 1] = val.view(torch.int32)
+    return out
+
+
 def _plan_ref(plan: Optional[SpmmPlan], n_rows: int, dev):
     if plan is None:
         return None
@@ -176,6 +202,11 @@ def _plan_ref(plan: Optional[SpmmPlan], n_rows: int, dev):
     if plan.device != dev:
         raise ValueError(f"the plan is on {plan.device}, the call runs on {dev}")
     return ctypes.addressof(plan.struct())
+
+
+def _check_edges(plan: Optional[SpmmPlan], col32: Tensor) -> None:
+    if plan is not None and plan.edges is not None and plan.edges.size(0) != col32.numel():
+        raise ValueError("the plan's packed edge list does not have one entry per edge")
 
 
 def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, n_cols: int,
@@ -224,6 +255,7 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
         _rows_f32(out, "out", dev)
         if out.size(0) != n_rows or out.size(1) != width:
             raise ValueError("out has the wrong shape")
+    _check_edges(plan, col32)
     fuse = None
     if relu_x or gate is not None:
         if gate is not None:
@@ -266,6 +298,7 @@ def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: T
             raise ValueError("add must be [>= n_rows, width]")
     if out is None:
         out = rows_empty(n_rows, width, dev)
+    _check_edges(plan, col32)
     with torch.cuda.device(dev):
         check(lib().incagg_spmm_csr_incagg_f32(
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(m_in), _ld(m_in),

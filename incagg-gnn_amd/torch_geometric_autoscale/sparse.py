@@ -249,7 +249,8 @@ class SparseTensor:
         self._value = value
         self._transposed = {}
         self._host = None
-        for k in ("_in_batch_view", "_device_copies", "_unweighted_view"):
+        for k in ("_in_batch_view", "_device_copies", "_unweighted_view", "_packed_edges",
+                  "_plan_twins"):
             self.__dict__.pop(k, None)
         return self
 
@@ -354,14 +355,47 @@ class SparseTensor:
             cache["rows"] = ops.SpmmPlan.build(self._rowptr32(), self.nnz())
         return cache["rows"]
 
+    def _with_packed_edges(self, base: "ops.SpmmPlan", tag, twin_key, col: Tensor,
+                           val: Optional[Tensor], stamp=None) -> "ops.SpmmPlan":
+        """``base`` carrying the packed edge list of (``col``, ``val``).  The packed arrays hold
+        edge VALUES, so they live on this object (not with the structure shared between
+        copies that differ in their values) and, like every array a recorded HIP graph may
+        hold, are allocated once per ``tag`` and refilled in place when ``stamp`` changes."""
+        if not col.is_cuda:
+            return base
+        packed = self.__dict__.setdefault("_packed_edges", {})
+        hit = packed.get(tag)
+        if hit is None or hit[1] != stamp:
+            packed[tag] = hit = (ops.pack_edges(col, val, None if hit is None else hit[0]), stamp)
+        twins = self.__dict__.setdefault("_plan_twins", {})
+        twin = twins.get(twin_key)
+        if twin is None or twin.edges is not hit[0] or twin.order is not base.order:
+            twin = twins[twin_key] = base.with_edges(hit[0])
+        return twin
+
+    def plan_edges(self) -> "ops.SpmmPlan":
+        """:meth:`plan` with the packed edge list of :meth:`device_csr`."""
+        _, col, val = self.device_csr()
+        return self._with_packed_edges(self.plan(), "rows", "rows", col, val)
+
+    def plan_edges_in_place(self, halo_ids: Tensor, n_in_batch: int) -> "ops.SpmmPlan":
+        """:meth:`plan` with the packed edge list of :meth:`col_in_place`'s column ids."""
+        col = self.col_in_place(halo_ids, n_in_batch)
+        key = ("in_place", halo_ids.numel(), n_in_batch)
+        stamp = (halo_ids.data_ptr(), halo_ids._version)
+        return self._with_packed_edges(self.plan(), key, key, col, self.device_csr()[2], stamp)
+
     def plan_t(self, reduce: str, lo: int, hi: int) -> "ops.SpmmPlan":
         """The same for rows [lo, hi) of the transposed CSR (device_csr_t prepares the two
-        windows the backward pass uses: all columns, and the in-batch columns)."""
+        windows the backward pass uses: all columns, and the in-batch columns), with the
+        packed edge list of the transposed arrays."""
         cache = self.__dict__.setdefault("_plans", {})
         key = ("t", lo, hi)
+        t_rowptr, t_col, t_val = self.device_csr_t(reduce)
         if key not in cache:
-            cache[key] = ops.SpmmPlan.build(self.device_csr_t(reduce)[0][lo:hi + 1], self.nnz())
-        return cache[key]
+            cache[key] = ops.SpmmPlan.build(t_rowptr[lo:hi + 1], self.nnz())
+        red = "mean" if reduce == "mean" else "sum"
+        return self._with_packed_edges(cache[key], ("t", red), ("t", red, lo, hi), t_col, t_val)
 
     def device_csr_t(self, reduce: str = "sum"):
         """Transposed CSR for dX = A^T dY, with 1/len(row) folded in for 'mean'."""

@@ -111,6 +111,12 @@ typedef struct incagg_spmm_plan {
    * (clear it before the plan is used again).  NULL: rows are zeroed by a launch in front. */
   float *combine;
   int64_t combine_floats;
+  /* Optional: the call's edge list once more, packed -- device int32[2 * nnz], entry e =
+   * (col[e], bit pattern of val[e], or of 1.0f without values), 8-byte aligned.  The 16-byte-
+   * aligned kernel then fetches an edge with one 8-byte load instead of two 4-byte ones (index
+   * loads are a fifth of its memory instructions).  It must agree with the col / val arrays
+   * of every call the plan is passed to (which other kernels still read); NULL: not used. */
+  const int32_t *edges;
 } incagg_spmm_plan;
 #define INCAGG_SPMM_COMBINE_SLOT_FLOATS 1056 /* 1024 accumulators + 32 per-slice arrival counters */
 

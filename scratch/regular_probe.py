@@ -44,6 +44,12 @@ for d in (8, 16, 32, 56, 64, 128, 512, 4096):
     rp2 = (torch.arange(rows + 1, device=dev, dtype=torch.int32) * d).contiguous()
     plan2 = ops.SpmmPlan.build(rp2, E)
     t = timeit(lambda: ops.spmm_csr(rp2, c, v, x, M, plan=plan2))
+    t1 = timeit(lambda: ops.spmm_csr(rp2, c, None, x, M, plan=plan2))
+    ident = ops.SpmmPlan(torch.arange(rows, device=dev, dtype=torch.int32), plan2.items,
+                         plan2.multi_rows, plan2.n_hub, plan2.n_items, plan2.n_multi,
+                         plan2.hub_threshold, plan2.segment_edges) if plan2.n_hub == 0 else plan2
+    t2 = timeit(lambda: ops.spmm_csr(rp2, c, v, x, M, plan=ident))
     print(f"rows of {d:4d} edges ({rows} rows, hub {plan2.n_hub} items {plan2.n_items}): {t:.1f} us  "
-          f"{rows * d * 1024 / t / 1e6:.2f} TB/s gathered", flush=True)
+          f"{rows * d * 1024 / t / 1e6:.2f} TB/s gathered | no weights {t1:.1f} | identity order {t2:.1f}",
+          flush=True)
 _lib.check_device_errors()

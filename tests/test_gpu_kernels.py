@@ -86,6 +86,44 @@ def test_spmm_matches_oracle(ops, dev, width, reduce, variant):
     _lib.check_device_errors()
 
 
+@pytest.mark.parametrize("width", [256, 41])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_spmm_packed_edge_list(ops, dev, width, weighted):
+    """A plan carrying the packed (col, val) pairs: the feature-sliced kernel reads its edges
+    from there -- same results, bit for bit where no atomics are involved, against the oracle
+    too; a packed list of the wrong length is refused."""
+    rng = np.random.default_rng(77 + width)
+    n_rows, n_cols = 300, 900
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, 9, hubs={5: 650, 17: 880},
+                                  empty_rows=(0, 299), weighted=weighted)
+    x = rng.standard_normal((n_cols, width)).astype(np.float32)
+    rp, c, v = _dev_csr(rowptr, col, val, dev)
+    _, xd = _pitched(x, dev, (width + 15) // 16 * 16 + 32, fill=0.0)
+    plan = ops.SpmmPlan.build(rp)
+    packed = ops.pack_edges(c, v)
+    assert packed.shape == (col.size, 2) and packed.dtype == torch.int32
+    y0 = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", plan=plan)
+    # poisoned col / val prove that the packed list is what the kernel reads
+    y1 = ops.spmm_csr(rp, torch.zeros_like(c), None if v is None else torch.zeros_like(v), xd,
+                      n_cols, "sum", plan=plan.with_edges(packed))
+    assert torch.equal(y0, y1)
+    _check(y1, cp.spmm_f64(rowptr, col, val, x, "sum"))
+    m_in = rng.standard_normal((n_rows, width)).astype(np.float32)
+    m_ag = rng.standard_normal((n_rows, width)).astype(np.float32)
+    rowptr2, col2, val2 = random_csr(rng, n_rows, n_rows, 9, hubs={5: 290}, weighted=weighted)
+    rp2, c2, v2 = _dev_csr(rowptr2, col2, val2, dev)
+    plan2 = ops.SpmmPlan.build(rp2)
+    (_, mind), (_, magd) = _pitched(m_in, dev, 1056, 0.0), _pitched(m_ag, dev, 1056, 0.0)
+    h0 = ops.spmm_csr_incagg(rp2, c2, v2, xd, mind, magd, "mean", plan=plan2)
+    h1 = ops.spmm_csr_incagg(rp2, c2, v2, xd, mind, magd, "mean",
+                             plan=plan2.with_edges(ops.pack_edges(c2, v2)))
+    assert torch.equal(h0, h1)
+    with pytest.raises(ValueError):
+        ops.spmm_csr(rp, c, v, xd, n_cols, "sum", plan=plan.with_edges(packed[:-1].contiguous()))
+    from torch_geometric_autoscale import _lib
+    _lib.check_device_errors()
+
+
 def _pitched(a, dev, pitch, fill=float("nan")):
     """``a`` on the device as a [rows, width] view of a [rows, pitch] matrix whose other
     columns hold ``fill``."""
