@@ -115,9 +115,10 @@ class _EmbedRelu(torch.autograd.Function):
         if bias is not None and x.is_cuda:
             # bias and relu ride in the GEMM epilogue (hipBLASLt): 104 us instead of 145 us for
             # the 128k x 100 -> 256 embedding of a products batch
-            h = torch._addmm_activation(bias, x, weight.t(), use_gelu=False,
-                                        out=ops.rows_empty(x.size(0), weight.size(0), x.device,
-                                                           x.dtype))
+            # (into a contiguous matrix: with a strided output the epilogue fusion is lost --
+            # GEMM + copy + clamp, 64 us more -- which costs more than the first aggregation
+            # gains from a padded row pitch of its source)
+            h = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
         else:
             h = (x @ weight.t() if bias is None else torch.addmm(bias, x, weight.t())).relu_()
         ctx.save_for_backward(x, weight, h)
@@ -133,7 +134,7 @@ class _EmbedRelu(torch.autograd.Function):
         elif ctx.grad_gated:
             # the consumer (the first aggregation's backward) zeroed it where h <= 0 already
             # and hands over a buffer of its own: used in place
-            g = d_all if d_all.is_contiguous() else d_all.contiguous()
+            g = d_all if d_all.stride(-1) == 1 else d_all.contiguous()
         else:
             g = torch.ops.aten.threshold_backward(d_all.contiguous(), h, 0)   # new tensor
         if d_batch is not None:
