@@ -55,11 +55,15 @@ def _tn_product(a: Tensor, b: Tensor) -> Tensor:
         return a.t() @ b
     slabs = _slab_count(rows)
     k = (rows // slabs) * slabs
-    out = torch.bmm(a[:k].unflatten(0, (slabs, k // slabs)).transpose(1, 2),
-                    b[:k].unflatten(0, (slabs, k // slabs))).sum(0)
-    if k < rows:
-        out.addmm_(a[k:].t(), b[k:])
-    return out
+    parts = torch.bmm(a[:k].unflatten(0, (slabs, k // slabs)).transpose(1, 2),
+                      b[:k].unflatten(0, (slabs, k // slabs)))
+    if not parts.is_cuda or parts.dtype != torch.float32:
+        out = parts.sum(0)
+        if k < rows:
+            out.addmm_(a[k:].t(), b[k:])
+        return out
+    # slab sum and remainder rows in one launch (a GEMM over < 10 rows costs a full launch)
+    return ops.tn_finish(parts, a[k:] if k < rows else None, b[k:] if k < rows else None)
 
 
 def _column_sums(x: Tensor) -> Tensor:

@@ -322,6 +322,29 @@ def rows_sub(a: Tensor, b: Tensor) -> Tensor:
     return out
 
 
+def tn_finish(parts: Tensor, a_tail: Optional[Tensor], b_tail: Optional[Tensor]) -> Tensor:
+    """``parts.sum(0) + a_tail^T @ b_tail`` (incagg_tn_finish_f32): the slab sum of a batched
+    weight-gradient product and its few remainder rows in one launch."""
+    _need_cuda(parts, "parts")
+    if parts.dim() != 3 or parts.dtype != torch.float32 or not parts.is_contiguous():
+        raise ValueError("parts must be a contiguous [slabs, m, n] float32 tensor")
+    s_, m, n = parts.shape
+    r = 0
+    if a_tail is not None and a_tail.size(0) > 0:
+        _rows_f32(a_tail, "a_tail", parts.device)
+        _rows_f32(b_tail, "b_tail", parts.device)
+        r = a_tail.size(0)
+        if b_tail.size(0) != r or a_tail.size(1) != m or b_tail.size(1) != n:
+            raise ValueError("remainder rows must be [r, m] and [r, n]")
+    out = torch.empty((m, n), dtype=torch.float32, device=parts.device)
+    with torch.cuda.device(parts.device):
+        check(lib().incagg_tn_finish_f32(
+            _ptr(parts), s_, _ptr(a_tail) if r else None, _ld(a_tail) if r else 0,
+            _ptr(b_tail) if r else None, _ld(b_tail) if r else 0, r, m, n, _ptr(out), n,
+            _stream_of(parts.device)))
+    return out
+
+
 # --------------------------------------------------------------------------- History rows
 def _device_visible(t: Tensor) -> bool:
     return t.is_cuda or t.is_pinned()

@@ -222,6 +222,16 @@ int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, int64_t ldb
                         int64_t n_rows, int64_t width, float *d, int64_t ldd,
                         void *stream);
 
+/* out[i, j] = sum_s parts[s, i, j] + sum_r a_tail[r, i] * b_tail[r, j]   (parts: S contiguous
+ * [m, n] matrices; a_tail [R, m] ld = lda, b_tail [R, n] ld = ldb; out [m, n] ld = ldo).
+ * Last step of a weight gradient a^T b over 10^4..10^5 rows, whose bulk runs as one batched
+ * GEMM over S row slabs: the slab sum and the few remainder rows in one launch.  No
+ * counterpart in the reference (its weight gradients are autograd's own matmuls behind
+ * main.py:81); dense-side helper of the training step. */
+int incagg_tn_finish_f32(const float *parts, int64_t n_parts, const float *a_tail, int64_t lda,
+                         const float *b_tail, int64_t ldb, int64_t n_tail, int64_t m, int64_t n,
+                         float *out, int64_t ldo, void *stream);
+
 /* ------------------------------------------------------------------ History rows
  * out[k,:] = emb[n_id[k],:]            (History.pull, history.py:33-39; the
  * gathered half of read_async, csrc/cuda/async_cuda.cu:95-110).

@@ -643,3 +643,23 @@ def test_chunk_push_with_activation(ops, dev):
     ops.copy_row_chunks(td, torch.from_numpy(x).to(dev), torch.from_numpy(offset),
                         torch.from_numpy(count), packed_is_src=True, relu=True)
     assert np.array_equal(td.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 256, 7), (9, 256, 256, 0), (32, 256, 100, 26), (6, 47, 256, 5)])
+def test_tn_finish_matches_torch(ops, dev, shape):
+    """Slab sum + remainder rows of a weight-gradient product in one launch."""
+    s_, m, n, r = shape
+    g = torch.Generator(device=dev).manual_seed(3)
+    parts = torch.randn(s_, m, n, device=dev, generator=g)
+    a = torch.randn(40, m + 8, device=dev, generator=g)[:r, :m]      # strided remainder rows
+    b = torch.randn(40, n + 32, device=dev, generator=g)[:r, :n]
+    got = ops.tn_finish(parts, a if r else None, b if r else None)
+    want = parts.double().sum(0) + (a.double().t() @ b.double() if r else 0)
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5)
+    # the product it finishes: a^T b over tall operands, against torch in fp64
+    from torch_geometric_autoscale.nn import _tn_product
+    rows = 16327
+    x = torch.randn(rows, m, device=dev, generator=g)
+    y = torch.randn(rows, n, device=dev, generator=g)
+    ref = (x.double().t() @ y.double())
+    assert torch.allclose(_tn_product(x, y).double(), ref, rtol=1e-4, atol=2e-3)
