@@ -361,6 +361,10 @@ def main():
     model = model.to(dev)
     if sharded:
         model.set_partition_context(ctx)
+        if not host_tables:
+            # out-of-batch rows are read in place as on a single GPU: own rows where they are,
+            # rows of peers received into the tail of the table shard
+            D.reserve_halo_tails(model, [bt["host"] for bt in batches])
     model.fused_incagg = args.fused_incagg
     g_cpu = torch.Generator().manual_seed(2)
     with torch.no_grad():

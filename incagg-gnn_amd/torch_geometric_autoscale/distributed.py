@@ -124,6 +124,43 @@ class HaloPlan:
             rows = out[:self.n_halo] if width is None else out[:self.n_halo, :width]
         return PendingHalo(work, rows, send)
 
+    @property
+    def n_remote(self) -> int:
+        """Out-of-batch rows of the batch that peers own."""
+        return sum(self.recv_counts)
+
+    def in_place_ids(self, n_local: int, device) -> Tensor:
+        """Row ids of the batch's out-of-batch rows in a table whose tail holds the received
+        rows (History.reserve_tail): own rows where they are, row ``n_local + k`` for the k-th
+        received one -- what the aggregation takes as ``halo_ids``."""
+        key = ("ids", str(device), n_local)
+        if key not in self._dev:
+            self._dev[key] = torch.cat([
+                self.own_local, n_local + torch.arange(self.n_remote, dtype=torch.int64)]
+            ).to(device)
+        return self._dev[key]
+
+    def start_exchange_in_place(self, history) -> "PendingHalo":
+        """:meth:`start_exchange` without a halo buffer: rows this rank owns are not moved at
+        all, rows of peers land in the tail of ``history``'s own allocation (whole rows at the
+        table's pitch, so that both ends of the transfer are contiguous).  Collective."""
+        base, n_local = history._base, history.num_embeddings
+        if base is None or history.tail_rows < self.n_remote:
+            raise RuntimeError(f"the table has room for {history.tail_rows} foreign rows, the "
+                               f"batch needs {self.n_remote} (History.reserve_tail)")
+        work = send = None
+        if self.ctx.world > 1 or self.ctx.exercise_collectives:
+            device = base.device if base.is_cuda or not torch.cuda.is_available() \
+                else torch.device("cuda", torch.cuda.current_device())
+            _, serve_local = self._on(device)
+            send = ops.gather_rows(base[:n_local], serve_local, device=device) \
+                if serve_local.numel() else torch.empty((0, base.size(1)), dtype=base.dtype,
+                                                        device=device)
+            recv = base[n_local:n_local + self.n_remote]
+            work = dist.all_to_all_single(recv, send, self.recv_counts, self.send_counts,
+                                          group=self.ctx.group, async_op=True)
+        return PendingHalo(work, None, send)
+
     def exchange(self, shard: Tensor, width: Optional[int] = None,
                  out: Optional[Tensor] = None) -> Optional[Tensor]:
         """:meth:`start_exchange` and wait: the rows, in plan order."""
@@ -220,6 +257,24 @@ def sharded_eval_batches(data: Data, ptr: Tensor, ctx: PartitionContext,
     rounds = ctx.max_over_ranks(len(groups))
     groups += [[] for _ in range(rounds - len(groups))]
     return [sharded_partition_batch(data, ptr, g, ctx) for g in groups]
+
+
+def reserve_halo_tails(model, batches) -> int:
+    """Gives every layer-input table of ``model`` room for the largest number of foreign
+    out-of-batch rows any of ``batches`` (SubData from :func:`sharded_partition_batch`) needs;
+    the push/pull step and the sweeps then read out-of-batch rows in place.  Returns that
+    number.  Collective."""
+    need, ctx = 0, None
+    for sub in batches:     # SubData, adjacencies or the plans themselves
+        plan = sub if isinstance(sub, HaloPlan) else getattr(
+            getattr(getattr(sub, "data", None), "adj_t", sub), "_halo_plan", None)
+        if plan is not None:
+            need, ctx = max(need, plan.n_remote), plan.ctx
+    if ctx is not None:     # every rank reserves (and so takes the in-place form of the exchange)
+        need = ctx.max_over_ranks(need)
+    for h in model.histories:
+        h.reserve_tail(need)
+    return need
 
 
 def allreduce_gradients(module: torch.nn.Module, ctx: PartitionContext) -> None:

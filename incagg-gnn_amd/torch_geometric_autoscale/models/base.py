@@ -213,8 +213,13 @@ class ScalableGNN(torch.nn.Module):
             # start now: out-of-batch rows are historical values either way, and the transfers
             # over xGMI then overlap with the layers' compute instead of preceding each of them.
             # (Rows a peer asks for are read before this step's own pushes.)
-            self._halo_pending = [self._current_plan.start_exchange(h.emb)
-                                  for h in self.histories[1:]]
+            # (tables with room for the foreign rows receive them in place, see _in_place_ok;
+            # the width probe stands for the layer input, which is as wide as its table)
+            self._halo_pending = [
+                self._current_plan.start_exchange_in_place(h)
+                if self._in_place_ok(h, h.emb[:0].to(self.device))
+                else self._current_plan.start_exchange(h.emb)
+                for h in self.histories[1:]]
 
         try:
             out, t_move = self.forward(x, adj_t, drift_norm, aggregate_combined, use_aggregation,
@@ -293,8 +298,14 @@ class ScalableGNN(torch.nn.Module):
         return out, 0.0
 
     def _in_place_ok(self, history, x: Tensor) -> bool:
-        if not self.halo_in_place or self._async or self.partition_ctx is not None:
+        if not self.halo_in_place or self._async:
             return False
+        if self.partition_ctx is not None:
+            # rows of peers must have a place behind the table's own rows (reserve_tail)
+            # (decided the same way on every rank: the exchange is collective and rows travel
+            # at the table's pitch in this form; the capacity itself is checked by the exchange)
+            if self._current_plan is None or history._base is None:
+                return False
         if not _same_device(history.emb.device, x.device):
             return False
         if type(self)._pre_aggregate is not ScalableGNN._pre_aggregate:
@@ -323,6 +334,14 @@ class ScalableGNN(torch.nn.Module):
             # (or are fetched now, when nothing was started: direct calls of this method)
             history.push(x.detach(), n_id[:batch_size], self._local(offset), count, relu=relu)
             plan = self._current_plan
+            if plan is not None and self._in_place_ok(history, x):
+                pending = (self._halo_pending.pop(0) if self._halo_pending
+                           else plan.start_exchange_in_place(history))
+                pending.wait()
+                if plan.n_halo == 0:
+                    return x, None, None
+                return (x, history.emb_with_tail[:, :x.size(1)],
+                        plan.in_place_ids(history.num_embeddings, history.emb.device))
             if self._halo_pending:
                 return x, self._halo_pending.pop(0).wait(), None
             return x, (None if plan is None else plan.exchange(history.emb)), None
@@ -558,7 +577,7 @@ class ScalableGNN(torch.nn.Module):
         pool = self.pool if use_pool else None
         pool_ag = self.pool_ag if use_pool else None
         last = self.num_layers - 1
-        in_place = (self.halo_in_place and not use_pool and not sharded
+        in_place = (self.halo_in_place and not use_pool
                     and _same_device(self.emb_device, self.device))
 
         def ids_on_device(data, n_id):     # one upload per (static) evaluation batch
@@ -598,27 +617,42 @@ class ScalableGNN(torch.nn.Module):
                     pool.async_pull(self.histories[i].emb, offset, count, n_id[batch_size:])
             for data, batch_size, n_id, offset, count, state in batches:
                 plan = getattr(data.adj_t, "_halo_plan", None) if sharded else None
+                # (every rank takes the same form of the exchange: rows travel at the table's
+                # pitch when they are received in place, at its width otherwise)
+                tail_ok = plan is not None and in_place and use_aggregation \
+                    and self.histories[i]._base is not None
                 if batch_size == 0:  # nothing of our own left, but peers still need serving
-                    plan.exchange(self.histories[i].emb)
+                    if tail_ok:
+                        plan.start_exchange_in_place(self.histories[i]).wait()
+                    else:
+                        plan.exchange(self.histories[i].emb)
                     continue
                 adj_t = data.adj_t.to(self.device)
                 halo = halo_ids = None
                 if use_pool:
                     x = pool.synchronize_pull()[:n_id.numel()]
-                elif in_place and use_aggregation and n_id.numel() > batch_size:
+                elif tail_ok or (plan is None and in_place and use_aggregation
+                                 and n_id.numel() > batch_size):
                     # in-batch rows by chunks (the update needs them); out-of-batch rows are
                     # read from the table by the aggregation itself
                     hist = self.histories[i]
+                    loc = self._local(offset)
                     if count.numel() == 1:      # one contiguous range: the table rows themselves
-                        o = int(offset[0])
+                        o = int(loc[0])
                         x = hist.emb[o:o + batch_size]
                     else:
                         x = torch.empty((batch_size, hist.embedding_dim), dtype=hist.emb.dtype,
                                         device=self.device)
-                        ops.copy_row_chunks(x, hist.emb, offset, count, packed_is_src=False,
+                        ops.copy_row_chunks(x, hist.emb, loc, count, packed_is_src=False,
                                             device=self.device)
-                    halo = hist.emb
-                    halo_ids = ids_on_device(data, n_id)[batch_size:]
+                    if plan is None:
+                        halo = hist.emb
+                        halo_ids = ids_on_device(data, n_id)[batch_size:]
+                    else:   # partition-parallel: peers' rows arrive behind the table's own
+                        plan.start_exchange_in_place(hist).wait()
+                        if plan.n_halo:
+                            halo = hist.emb_with_tail
+                            halo_ids = plan.in_place_ids(hist.num_embeddings, hist.emb.device)
                 else:
                     x = self._pull_layer_input(self.histories[i], batch_size, n_id, offset, count,
                                                plan)

@@ -57,14 +57,16 @@ def row_pitch(width: int) -> int:
     return width + 32
 
 
-def rows_empty(rows: int, width: int, device, dtype=torch.float32) -> Tensor:
+def rows_empty(rows: int, width: int, device, dtype=torch.float32, with_base: bool = False):
     """Uninitialised ``[rows, width]`` matrix with the row pitch of :func:`row_pitch` (a view
-    of a wider allocation when the pitch differs from the width)."""
+    of a wider allocation when the pitch differs from the width).  ``with_base``: also the
+    contiguous ``[rows, pitch]`` matrix it is a view of."""
     pitch = row_pitch(width) if torch.device(device).type == "cuda" else width
     buf = torch.empty((rows, pitch), dtype=dtype, device=device)
     # (.data: same memory, but not a view in autograd's books -- results of custom autograd
     # functions that are views may not be updated in place, e.g. by a following relu_)
-    return buf if pitch == width else buf[:, :width].data
+    out = buf if pitch == width else buf[:, :width].data
+    return (out, buf) if with_base else out
 
 
 def _need_cuda(t: Tensor, name: str) -> None:

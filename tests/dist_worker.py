@@ -21,6 +21,7 @@ from cpu_shim import cpu_kernels  # noqa: E402
 def main():
     out_dir = sys.argv[1]
     names = sys.argv[2].split(",")
+    in_place = len(sys.argv) > 3 and sys.argv[3] == "in_place"
     dist.init_process_group("gloo")
     from torch_geometric_autoscale import distributed as D
     data, ptr = mc.make_graph()
@@ -33,6 +34,21 @@ def main():
             model.set_partition_context(ctx)
             model.eval()
             batches = D.sharded_eval_batches(data, ptr, ctx, batch_size=1)
+            calls = {"in_place": 0, "buffer": 0}
+            if in_place:
+                # room for the foreign rows behind every table's own rows: out-of-batch rows
+                # are then read in place (own ones where they are, foreign ones in the tail)
+                train_sub = D.sharded_partition_batch(data, ptr, [ctx.part_lo], ctx)
+                need = D.reserve_halo_tails(model, batches + [train_sub])
+                assert all(h.tail_rows == need for h in model.histories)
+                originals = {}
+                for attr, key in (("start_exchange_in_place", "in_place"), ("start_exchange", "buffer")):
+                    originals[attr] = getattr(D.HaloPlan, attr)
+
+                    def counted(self, *a, _f=originals[attr], _k=key, **k):
+                        calls[_k] += 1
+                        return _f(self, *a, **k)
+                    setattr(D.HaloPlan, attr, counted)
             out = model.mini_inference_vr(batches)
             result[f"{name}/out"] = out.clone()
             for i in range(model.num_layers):
@@ -54,6 +70,10 @@ def main():
             ret = model.VR_call(sub.data.x, sub.data.adj_t, sub.batch_size, sub.n_id, sub.offset,
                                 sub.count)
             result[f"{name}/vr_out"] = ret["out"].detach().clone()
+            if in_place:
+                result[f"{name}/calls"] = dict(calls)
+                for attr, fn in originals.items():
+                    setattr(D.HaloPlan, attr, fn)
     torch.save(result, os.path.join(out_dir, f"rank{ctx.rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

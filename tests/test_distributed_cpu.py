@@ -25,15 +25,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("mode", ["buffer", "in_place"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_sharded_run_matches_single_process(world, tmp_path):
+def test_sharded_run_matches_single_process(world, mode, tmp_path):
+    """``mode``: out-of-batch rows gathered into a halo buffer, or read in place -- own rows
+    where they are in the table shard, rows of peers received into the shard's tail."""
     env = dict(os.environ, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), ",".join(NAMES)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), ",".join(NAMES), mode]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     ranks = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    if mode == "in_place":      # the in-place exchange is what ran (where the model allows it)
+        for res in ranks:
+            assert res["gcn2/calls"]["in_place"] > 0 and res["gcn2/calls"]["buffer"] == 0, res["gcn2/calls"]
 
     from torch_geometric_autoscale.loader import partition_batch
     import torch_geometric_autoscale as tga

@@ -30,7 +30,7 @@ def rccl():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tables", ["hbm", "host"])
+@pytest.mark.parametrize("tables", ["hbm", "hbm_in_place", "host"])
 @pytest.mark.parametrize("name", ["gcn2", "sage", "appnp"])
 def test_sharded_path_over_rccl_matches_unsharded(name, tables, rccl):
     import torch_geometric_autoscale as tga
@@ -46,6 +46,8 @@ def test_sharded_path_over_rccl_matches_unsharded(name, tables, rccl):
 
     ctx = D.PartitionContext(ptr, exercise_collectives=True)
     assert (ctx.rank, ctx.world, ctx.local_rows) == (0, 1, data.num_nodes)
+    in_place = tables == "hbm_in_place"
+    tables = "hbm" if in_place else tables
     emb_device = dev if tables == "hbm" else None
     model = mc.make_model(name, data, f_in, 5, emb_device=emb_device, pool_size=2,
                           buffer_size=4 * data.num_nodes if tables == "host" else None).to(dev)
@@ -55,6 +57,16 @@ def test_sharded_path_over_rccl_matches_unsharded(name, tables, rccl):
         assert model.histories[0].emb.is_pinned() and not model.histories[0].emb.is_cuda
     model.eval()
     batches = D.sharded_eval_batches(data, ptr, ctx, batch_size=1)
+    calls = {"in_place": 0}
+    if in_place:    # out-of-batch rows read in place from the shard (+ its tail for peers' rows)
+        D.reserve_halo_tails(model, batches)
+        assert all(h._base is not None for h in model.histories)
+        original = D.HaloPlan.start_exchange_in_place
+
+        def counted(self, *a, **k):
+            calls["in_place"] += 1
+            return original(self, *a, **k)
+        D.HaloPlan.start_exchange_in_place = counted
     out = model.mini_inference_vr(batches)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), out_ref.cpu().numpy(), **TOL)
@@ -89,3 +101,7 @@ def test_sharded_path_over_rccl_matches_unsharded(name, tables, rccl):
         np.testing.assert_allclose(grads[0], grads[1], rtol=1e-3, atol=1e-5)
     torch.cuda.synchronize()
     _lib.check_device_errors()
+    if in_place:
+        D.HaloPlan.start_exchange_in_place = original
+        if name == "gcn2":
+            assert calls["in_place"] > 0
