@@ -2,7 +2,7 @@
 import cProfile, pstats, sys, os, io
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.argv = ["bench.py", "--no-cpu-baseline", "--sweep", "off", "--steps", "60"]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--sweep", "off", "--epoch-pass", "off", "--steps", "60", "--graphs", os.environ.get("GRAPHS", "off")]
 os.environ["BENCH_PRIME_SECONDS"] = "0.5"
 import bench
 pr = cProfile.Profile()
