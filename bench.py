@@ -315,6 +315,12 @@ def main():
     parts_lo, parts_hi = rank * args.parts // world, (rank + 1) * args.parts // world
     my_parts = list(range(parts_lo, parts_hi))
     groups = [my_parts[i:i + args.batch_parts] for i in range(0, len(my_parts), args.batch_parts)]
+    if sharded:
+        # every rank takes part in every collective (plan building, halo exchanges, gradient
+        # all-reduces) the same number of times: all ranks use as many batches as the rank with
+        # the fewest (the shares differ by at most one partition)
+        shares = [(r + 1) * args.parts // world - r * args.parts // world for r in range(world)]
+        groups = groups[:min(-(-sh // args.batch_parts) for sh in shares)]
     epoch_pass = args.epoch_pass == "on" or (args.epoch_pass == "auto" and not sharded)
     need = len(groups) if epoch_pass else min(len(groups), args.steps + args.warmup)
     host_tables = args.tables == "host"
@@ -380,18 +386,53 @@ def main():
                     h.emb.normal_(0, 0.1)
     # (staging pools run on side streams with a host worker thread: nothing to record)
     use_graphs = (args.graphs == "on" or (args.graphs == "auto" and not sharded)) and not host_tables
+    # Partition-parallel steps are not recorded whole (this torch build cannot record the
+    # asynchronous collectives): the collectives -- halo exchanges at the top, the gradient
+    # all-reduce at the end -- are issued eagerly around ONE recorded graph of everything between
+    # them (forward with the foreign rows already in the table tails, loss, backward).
+    split_graphs = sharded and args.graphs != "off" and not host_tables
+    if split_graphs:
+        use_graphs = False
     # one launch per step; capturable: the step counter lives on the device
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graphs)
     crit = torch.nn.CrossEntropyLoss()
     model.train()
     setup_s = time.perf_counter() - t_setup
 
+    flat_grads = None
+
     def step(i):
         k = i % len(batches)
+        if flat_grads is not None:
+            return split_step(k, replay=True)
         if graphs is not None and k in graphs:
             graphs.replay(k)
             return batches[k]["edges"]
         return eager_step(k)
+
+    def split_body(k):      # the collective-free part of a partition-parallel step
+        bt = batches[k]
+        if args.mode == "vr":
+            out = model.VR_call(bt["x"], bt["adj"], bt["b"], bt["nid_dev"], bt["offset"],
+                                bt["count"])["out"]
+        else:
+            out = model(bt["x"], bt["adj"], bt["b"], bt["nid_dev"], bt["offset"], bt["count"],
+                        halo_ready=True)["out"]
+        opt.zero_grad(set_to_none=False)    # gradients are views of one flat buffer
+        crit(out, bt["y"]).backward()
+
+    def split_step(k, replay):
+        bt = batches[k]
+        if args.mode != "vr":
+            for pending in model.start_halo_exchanges(bt["adj"]):
+                pending.wait()
+        if replay:
+            graphs.replay(k)
+        else:
+            split_body(k)
+        D.allreduce_flat_gradients(flat_grads, ctx)
+        opt.step()
+        return bt["edges"]
 
     def eager_step(k):
         bt = batches[k]
@@ -419,6 +460,28 @@ def main():
         clock.counting = False
         bt["edges"] = clock.edges
     torch.cuda.synchronize()
+    if split_graphs:
+        from torch_geometric_autoscale.graphs import StepGraphs
+        flat_grads = D.flatten_gradients(model)
+        graphs = StepGraphs(dev)
+        for k in range(len(batches)):
+            graphs.warm(lambda: split_step(k, replay=False), times=1)
+        D.quiesce_collectives()
+        recorded = True
+        try:
+            for k in range(len(batches)):
+                graphs.capture(k, lambda: split_body(k), capture_error_mode="thread_local")
+            torch.cuda.synchronize()
+        except Exception as exc:     # fall back to eagerly issued steps, on every rank alike
+            print(f"rank {rank}: recording the step failed ({exc!r}); steps are issued eagerly",
+                  file=sys.stderr, flush=True)
+            recorded = False
+        agreed = torch.tensor([int(recorded)], device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if not int(agreed):
+            graphs = flat_grads = None
+            for p_ in model.parameters():
+                p_.grad = None
     if use_graphs:
         # every batch's step is recorded once (untimed) and replayed from then on
         from torch_geometric_autoscale.graphs import StepGraphs
@@ -485,16 +548,17 @@ def main():
         e.record()
         torch.cuda.synchronize()
         spin_per_ms = 20_000_000 / s.elapsed_time(e)
+        unrecorded = eager_step if flat_grads is None else (lambda k: split_step(k, replay=False))
         clock.enabled = True        # (issue time measured with the events in place)
         t_issue = time.perf_counter()
-        eager_step(args.warmup % len(batches))
+        unrecorded(args.warmup % len(batches))
         t_issue = (time.perf_counter() - t_issue) * 1e3
         torch.cuda.synchronize()
         clock.records.clear()
         spin = int(spin_per_ms * 1.5 * t_issue)
         for i in range(args.steps):
             torch.cuda._sleep(spin)
-            eager_step((args.warmup + i) % len(batches))
+            unrecorded((args.warmup + i) % len(batches))
         torch.cuda.synchronize()
         clock.enabled = False
         kernel_timing = ("HIP events around every aggregation launch in an eager pass over the "
@@ -579,8 +643,10 @@ def main():
                     ", row-sharded History tables, one all-to-all of halo rows per layer, "
                     "flat gradient all-reduce" if sharded else ""),
                 "setup_seconds": round(setup_s, 1),
-                "step_launch": ("one HIP graph replay per step (recorded once per batch, untimed)"
-                                if graphs is not None else "eager"),
+                "step_launch": ("collectives issued eagerly around one HIP graph replay of "
+                                "forward + loss + backward per step" if flat_grads is not None
+                                else "one HIP graph replay per step (recorded once per batch, "
+                                "untimed)" if graphs is not None else "eager"),
             },
             "epoch": {
                 "train_epoch_seconds": epoch_s if epoch_s is not None

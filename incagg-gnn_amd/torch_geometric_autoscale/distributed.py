@@ -295,6 +295,43 @@ def allreduce_gradients(module: torch.nn.Module, ctx: PartitionContext) -> None:
         off += n
 
 
+def quiesce_collectives(seconds: float = 1.5) -> None:
+    """Waits until every collective issued so far has completed AND the process group's
+    watchdog thread has retired its bookkeeping for them (it polls their events a few times per
+    second, and an event poll while a stream records a HIP graph is an error on some builds):
+    call it between the last eager collective and a graph recording."""
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    time.sleep(seconds)
+
+
+def flatten_gradients(module: torch.nn.Module) -> Tensor:
+    """Makes every parameter's ``.grad`` a view into ONE flat buffer (zero-filled) and returns
+    the buffer: the gradient all-reduce is then a single collective on it, with no
+    concatenation before and no copies after.  Use ``zero_grad(set_to_none=False)`` from then
+    on, so that backward passes keep accumulating into the views."""
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return torch.zeros(0)
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype,
+                       device=params[0].device)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    return flat
+
+
+def allreduce_flat_gradients(flat: Tensor, ctx: PartitionContext) -> None:
+    """Mean over the ranks of a buffer from :func:`flatten_gradients`."""
+    if ctx.world == 1 and not ctx.exercise_collectives:
+        return
+    dist.all_reduce(flat, group=ctx.group)
+    if ctx.world > 1:
+        flat.div_(ctx.world)
+
+
 def broadcast_parameters(module: torch.nn.Module, ctx: PartitionContext, src: int = 0) -> None:
     """Replicates rank ``src``'s weights (and batch-norm statistics) on every rank."""
     if ctx.world == 1:

@@ -43,11 +43,16 @@ class StepGraphs:
                 fn()
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
-    def capture(self, key: Hashable, fn: Callable[[], None]) -> None:
+    def capture(self, key: Hashable, fn: Callable[[], None],
+                capture_error_mode: str = "global") -> None:
         """Records one execution of ``fn`` (all tensors it reads must stay alive and keep
-        their addresses; whatever it allocates lives in the shared pool)."""
+        their addresses; whatever it allocates lives in the shared pool).
+        ``capture_error_mode="thread_local"``: other threads may keep calling the HIP runtime
+        while this one records -- needed next to a ``torch.distributed`` process group, whose
+        watchdog thread polls the events of earlier collectives."""
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+        with torch.cuda.graph(graph, pool=self.pool, stream=self.stream,
+                              capture_error_mode=capture_error_mode):
             fn()
         self.graphs[key] = graph
 

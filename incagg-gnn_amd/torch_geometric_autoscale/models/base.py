@@ -126,6 +126,17 @@ class ScalableGNN(torch.nn.Module):
         self.partition_ctx = ctx
         return self
 
+    def start_halo_exchanges(self, adj_t: SparseTensor) -> list:
+        """Partition-parallel, tables with tails: starts the in-place exchanges of every layer
+        for the batch ``adj_t`` belongs to and returns them (``PendingHalo``; ``wait()`` orders
+        the current stream behind the transfer).  Collective.  Together with
+        ``model(..., halo_ready=True)`` this splits a step into its collectives and a
+        collective-free part."""
+        plan = getattr(adj_t, "_halo_plan", None)
+        if self.partition_ctx is None or plan is None:
+            raise RuntimeError("needs a partition context and a batch from sharded_partition_batch")
+        return [plan.start_exchange_in_place(h) for h in self.histories[1:]]
+
     def _local(self, offset: Optional[Tensor]) -> Optional[Tensor]:
         ctx = self.partition_ctx
         return offset if ctx is None or offset is None else offset - ctx.row_lo
@@ -179,12 +190,17 @@ class ScalableGNN(torch.nn.Module):
                  batch_size: Optional[int] = None, n_id: Optional[Tensor] = None,
                  offset: Optional[Tensor] = None, count: Optional[Tensor] = None,
                  loader=None, drift_norm: int = 2, aggregate_combined: bool = True,
-                 use_aggregation: bool = True, **kwargs):
+                 use_aggregation: bool = True, halo_ready: bool = False, **kwargs):
         r"""Push/pull forward (models/base.py:126-240): starts the pulls of the
         out-of-batch rows of every layer, runs :meth:`forward`, waits for the pushes.
-        Returns a dict whose ``'out'`` entry is the model output."""
+        Returns a dict whose ``'out'`` entry is the model output.
+
+        ``halo_ready`` (partition-parallel, tables with tails): the caller has run
+        :meth:`start_halo_exchanges` for this batch and waited for them; the call then
+        contains no collective and can be recorded into a HIP graph."""
         if loader is not None:
             return self.mini_inference(loader, use_aggregation)
+        self._halo_ready = bool(halo_ready)
 
         self._async = (self.pool is not None and batch_size is not None and n_id is not None
                        and offset is not None and count is not None)
@@ -207,7 +223,12 @@ class ScalableGNN(torch.nn.Module):
         if self._async and use_aggregation:
             for hist in self.histories[1:]:
                 self.pool.async_pull(hist.emb, None, None, n_id[batch_size:])
-        if (self.partition_ctx is not None and self._current_plan is not None and use_aggregation
+        if self._halo_ready:
+            if self.partition_ctx is None or self._current_plan is None or not all(
+                    self._in_place_ok(h, h.emb[:0].to(self.device)) for h in self.histories[1:]):
+                raise RuntimeError("halo_ready needs a partition context, a batch with a halo plan "
+                                   "and tables that receive foreign rows in place (reserve_tail)")
+        elif (self.partition_ctx is not None and self._current_plan is not None and use_aggregation
                 and batch_size is not None):
             # Like the pool's pulls above (models/base.py:186-188), the exchanges of ALL layers
             # start now: out-of-batch rows are historical values either way, and the transfers
@@ -335,9 +356,10 @@ class ScalableGNN(torch.nn.Module):
             history.push(x.detach(), n_id[:batch_size], self._local(offset), count, relu=relu)
             plan = self._current_plan
             if plan is not None and self._in_place_ok(history, x):
-                pending = (self._halo_pending.pop(0) if self._halo_pending
-                           else plan.start_exchange_in_place(history))
-                pending.wait()
+                if not getattr(self, "_halo_ready", False):
+                    pending = (self._halo_pending.pop(0) if self._halo_pending
+                               else plan.start_exchange_in_place(history))
+                    pending.wait()
                 if plan.n_halo == 0:
                     return x, None, None
                 return (x, history.emb_with_tail[:, :x.size(1)],

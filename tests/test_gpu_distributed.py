@@ -105,3 +105,86 @@ def test_sharded_path_over_rccl_matches_unsharded(name, tables, rccl):
         D.HaloPlan.start_exchange_in_place = original
         if name == "gcn2":
             assert calls["in_place"] > 0
+
+
+def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
+    """A partition-parallel step split at its collectives: halo exchanges (into the table
+    tails) and the flat gradient all-reduce are issued eagerly, everything between them --
+    forward with ``halo_ready=True``, loss, backward into the flat gradient buffer -- is ONE
+    HIP graph recorded next to the live RCCL process group.  Weights and tables after three
+    such steps over two batches equal those of eagerly issued partition-parallel steps."""
+    import copy
+    import torch_geometric_autoscale as tga
+    from torch_geometric_autoscale import _lib, distributed as D
+    from torch_geometric_autoscale.graphs import StepGraphs
+    dev = rccl
+    data, ptr = mc.make_graph()
+    f_in = data.x.size(1)
+    ctx = D.PartitionContext(ptr, exercise_collectives=True)
+    base = mc.make_model("gcn2", data, f_in, 5, emb_device=dev).to(dev)
+    subs = [D.sharded_partition_batch(data, ptr, [p], ctx) for p in (2, 5)]
+    steps = [0, 1, 0]
+
+    def prepared():
+        model = copy.deepcopy(base)
+        for h_new, h_old in zip(list(model.histories) + list(model.histories_ag),
+                                list(base.histories) + list(base.histories_ag)):
+            h_new.emb = h_old.emb.clone()       # (tables are plain attributes: not deep-copied)
+        model.set_partition_context(ctx)
+        D.reserve_halo_tails(model, subs)
+        model.train()
+        return model, torch.optim.SGD(model.parameters(), lr=0.05)
+
+    def inputs(sub):
+        return (sub.data.x.to(dev), sub.data.adj_t.to(dev), sub.batch_size, sub.n_id, sub.offset,
+                sub.count), sub.data.y[:sub.batch_size].to(dev)
+
+    # eager partition-parallel steps
+    eager, opt = prepared()
+    for k in steps:
+        args, y = inputs(subs[k])
+        loss = torch.nn.functional.cross_entropy(eager(*args)["out"], y)
+        opt.zero_grad()
+        loss.backward()
+        D.allreduce_gradients(eager, ctx)
+        opt.step()
+
+    # the same steps, split at the collectives
+    model, opt = prepared()
+    flat = D.flatten_gradients(model)
+    prepared_inputs = [inputs(s) for s in subs]
+
+    def body(k):
+        args, y = prepared_inputs[k]
+        out = model(*args, halo_ready=True)["out"]
+        opt.zero_grad(set_to_none=False)
+        torch.nn.functional.cross_entropy(out, y).backward()
+
+    def step(k, replay):
+        for pending in model.start_halo_exchanges(prepared_inputs[k][0][1]):
+            pending.wait()
+        graphs.replay(k) if replay else body(k)
+        D.allreduce_flat_gradients(flat, ctx)
+        opt.step()
+
+    snapshot = copy.deepcopy(model.state_dict())
+    tables = [h.emb_with_tail.clone() for h in model.histories]
+    graphs = StepGraphs(dev)
+    for k in range(len(subs)):                  # lazily built per-batch structures, then record
+        graphs.warm(lambda: step(k, replay=False), times=1)
+    D.quiesce_collectives()
+    for k in range(len(subs)):
+        graphs.capture(k, lambda: body(k), capture_error_mode="thread_local")
+    torch.cuda.synchronize()
+    model.load_state_dict(snapshot)             # back to the start (in place: addresses stay)
+    for h, t in zip(model.histories, tables):
+        h.emb_with_tail.copy_(t)
+    for k in steps:
+        step(k, replay=True)
+    torch.cuda.synchronize()
+    for (name, p), q in zip(model.named_parameters(), eager.parameters()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(),
+                                   rtol=1e-4, atol=1e-5, err_msg=name)
+    for h, g in zip(model.histories, eager.histories):
+        np.testing.assert_allclose(h.emb.cpu().numpy(), g.emb.cpu().numpy(), **TOL)
+    _lib.check_device_errors()
