@@ -671,7 +671,7 @@ def main():
                 "gather_bound_GBps": ks["gather_GBps"],
                 "timing": kernel_timing,
             }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # (reported on single-GPU runs only)
             host = []
             for b_ in batches[:4]:
                 rp, c, v = b_["host"].csr()
