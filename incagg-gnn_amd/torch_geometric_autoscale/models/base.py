@@ -548,13 +548,20 @@ class ScalableGNN(torch.nn.Module):
                                      pin_memory=on_host and torch.cuda.is_available())
         return self.__out
 
-    def _push_rows(self, table: Tensor, rows: Tensor, offset: Tensor, count: Tensor, pool) -> None:
+    def _push_rows(self, table: Tensor, rows: Tensor, offset: Tensor, count: Tensor, pool,
+                   relu: bool = False) -> None:
+        """``relu``: ``rows`` holds pre-activations, ``max(0, rows)`` is what gets stored (on the
+        GPU path by the copy kernel itself)."""
+        if relu and not (pool is None and rows.is_cuda):
+            rows = torch.relu(rows)
+            relu = False
         if pool is not None:
             if rows.size(1) < table.size(1):  # pad to the table width (models/gcn.py:355-365)
                 rows = F.pad(rows, (0, table.size(1) - rows.size(1)))
             pool.async_push(rows, offset, count, table)
         elif rows.is_cuda:
-            ops.copy_row_chunks(table, rows, offset, count, packed_is_src=True, device=rows.device)
+            ops.copy_row_chunks(table, rows, offset, count, packed_is_src=True, device=rows.device,
+                                relu=relu)
         else:
             src = 0
             for o, c in zip(offset.tolist(), count.tolist()):
@@ -602,6 +609,8 @@ class ScalableGNN(torch.nn.Module):
         in_place = (self.halo_in_place and not use_pool
                     and _same_device(self.emb_device, self.device))
 
+        defer = self._defers_relu()
+
         def ids_on_device(data, n_id):     # one upload per (static) evaluation batch
             return _ids_on(data.adj_t, n_id, self.device)
 
@@ -611,9 +620,14 @@ class ScalableGNN(torch.nn.Module):
                    else x[:batch_size])
             if with_aggregates:
                 self._push_rows(self.histories_ag[i].emb, agg, offset, count, pool_ag)
+            # a relu that ends the layer is left to the push where the model allows it (every
+            # later reader of these rows -- the next layer of the sweep, training steps --
+            # reads them from the table)
+            state['defer_relu'] = defer and i < last
             out = self._update(i, agg, x, state)[:batch_size]
             target = self._out if i == last else self.histories[i + 1].emb
-            self._push_rows(target, out, offset, count, pool)
+            self._push_rows(target, out, offset, count, pool,
+                            relu=state.pop('relu_deferred', False))
 
         for data, batch_size, n_id, offset, count, state in batches:
             if batch_size == 0:      # padding batch of a partition-parallel run
