@@ -21,6 +21,27 @@ def _ptr(t: Optional[Tensor]):
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
 
+class _on_device:
+    """``with torch.cuda.device(device)`` that costs nothing when ``device`` is already the
+    current one (every call of a training step; the context manager's enter / exit pair is a
+    measurable part of an entry point's host cost)."""
+    __slots__ = ("_ctx",)
+
+    def __init__(self, device):
+        idx = device.index
+        self._ctx = None if idx is None or idx == torch.cuda.current_device() \
+            else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
 def _stream_of(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -165,7 +186,7 @@ class SpmmPlan:
         multi = torch.empty(max(min(n_rows, cap), 1), dtype=torch.int32, device=dev)
         counts = (ctypes.c_int64 * 5)()
         if dev.type == "cuda":
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 need = L.incagg_spmm_plan_device_scratch_bytes(n_rows)
                 check(need)
                 _, _, scratch = _build_workspace(dev, 0, need)
@@ -267,7 +288,7 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
         fuse_struct = _lib.SpmmFuseStruct(1 if relu_x else 0, _ptr(gate),
                                           0 if gate is None else _ld(gate))
         fuse = ctypes.addressof(fuse_struct)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         check(lib().incagg_spmm_csr_f32(
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(x_halo),
             0 if x_halo is None else _ld(x_halo), n_split, n_rows, n_cols, width,
@@ -301,7 +322,7 @@ def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: T
     if out is None:
         out = rows_empty(n_rows, width, dev)
     _check_edges(plan, col32)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         check(lib().incagg_spmm_csr_incagg_f32(
             _ptr(rowptr32), _ptr(col32), _ptr(val), _ptr(x), _ld(x), _ptr(m_in), _ld(m_in),
             _ptr(m_ag), _ld(m_ag), n_rows, width, REDUCE[reduce], float(scale), _ptr(add),
@@ -318,7 +339,7 @@ def rows_sub(a: Tensor, b: Tensor) -> Tensor:
     if b.size(0) < n or b.size(1) < w:
         raise ValueError("b is smaller than a")
     out = torch.empty((n, w), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on_device(a.device):
         check(lib().incagg_rows_sub_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), n, w, _ptr(out), _ld(out),
                                         _stream_of(a.device)))
     return out
@@ -339,7 +360,7 @@ def tn_finish(parts: Tensor, a_tail: Optional[Tensor], b_tail: Optional[Tensor])
         if b_tail.size(0) != r or a_tail.size(1) != m or b_tail.size(1) != n:
             raise ValueError("remainder rows must be [r, m] and [r, n]")
     out = torch.empty((m, n), dtype=torch.float32, device=parts.device)
-    with torch.cuda.device(parts.device):
+    with _on_device(parts.device):
         check(lib().incagg_tn_finish_f32(
             _ptr(parts), s_, _ptr(a_tail) if r else None, _ld(a_tail) if r else 0,
             _ptr(b_tail) if r else None, _ld(b_tail) if r else 0, r, m, n, _ptr(out), n,
@@ -371,7 +392,7 @@ def gather_rows(emb: Tensor, n_id: Tensor, out: Optional[Tensor] = None,
         _rows_f32(out, "out", dev)
         if out.size(0) < k or out.size(1) < w:
             raise ValueError("out too small")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         check(lib().incagg_gather_rows_f32(_ptr(emb), _ld(emb), emb.size(0), _ptr(n_id), k, w,
                                            _ptr(out), _ld(out), _stream_of(dev)))
     return out
@@ -389,7 +410,7 @@ def scatter_rows(emb: Tensor, n_id: Tensor, x: Tensor) -> None:
         raise TypeError("n_id must be a contiguous 1-D int64 tensor")
     if x.size(0) != n_id.numel() or x.size(1) > emb.size(1):
         raise ValueError("x must be [len(n_id), <= emb width]")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         check(lib().incagg_scatter_rows_f32(_ptr(emb), _ld(emb), emb.size(0), _ptr(n_id),
                                             n_id.numel(), x.size(1), _ptr(x), _ld(x),
                                             _stream_of(dev)))
@@ -418,7 +439,7 @@ def copy_row_chunks(dst: Tensor, src: Tensor, offset: Tensor, count: Tensor,
     offset, count = _host_i64(offset, "Offset"), _host_i64(count, "Count")
     if offset.numel() != count.numel():
         raise RuntimeError("Size mismatch")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         check(lib().incagg_copy_row_chunks_f32(
             _ptr(dst), _ld(dst), dst.size(0), dst.size(1), _ptr(src), _ld(src), src.size(0),
             src.size(1), _ptr(offset), _ptr(count), offset.numel(), 1 if packed_is_src else 0,
@@ -547,7 +568,7 @@ def relabel_one_hop_device(rowptr: Tensor, col: Tensor, value: Optional[Tensor],
         raise RuntimeError("Value tensor must be a contiguous one-dimensional float32 device tensor")
     n_nodes, n_idx = rowptr.numel() - 1, idx.numel()
     L = lib()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         stream = _stream_of(dev)
         if edge_capacity is None:
             need = 4096 + 16 * (n_idx + 2)
@@ -595,7 +616,7 @@ def csr_transpose_device(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor],
     t_rowptr = torch.empty(n_cols + 1, dtype=torch.int32, device=dev)
     t_col = torch.empty(nnz, dtype=torch.int32, device=dev)
     t_val = torch.empty(nnz, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _, _, scratch = _build_workspace(dev, 0, need)
         check(L.incagg_csr_transpose_device(
             _ptr(rowptr32) or rowptr32.data_ptr(), _ptr(col32), _ptr(val), n_rows, n_cols, nnz,
@@ -656,7 +677,7 @@ def read_async(src: Tensor, offset: Optional[Tensor], count: Optional[Tensor], i
             buffer.numel() // max(buffer.size(0), 1) != row_elems:
         raise RuntimeError("Source, target and buffer rows must have the same size")
     stream = _non_default_stream(dst.device)
-    with torch.cuda.device(dst.device):
+    with _on_device(dst.device):
         check(lib().incagg_stage_read_async(
             _ptr(src), src.size(0), row_elems * src.element_size(), _ptr(offset), _ptr(count),
             n_chunks, _ptr(index), index.numel(), _ptr(dst), dst.size(0), _ptr(buffer),
@@ -694,7 +715,7 @@ def write_async(src: Tensor, offset: Tensor, count: Tensor, dst: Tensor) -> None
     if dst.numel() // max(dst.size(0), 1) != row_elems:
         raise RuntimeError("Source and target rows must have the same size")
     stream = _non_default_stream(src.device)
-    with torch.cuda.device(src.device):
+    with _on_device(src.device):
         check(lib().incagg_stage_write_async(
             _ptr(src), src.size(0), row_elems * src.element_size(), _ptr(offset), _ptr(count),
             offset.numel(), _ptr(dst), dst.size(0), stream))
