@@ -610,6 +610,14 @@ class ScalableGNN(torch.nn.Module):
                     and _same_device(self.emb_device, self.device))
 
         defer = self._defers_relu()
+        # per-batch results that every layer of the sweep reuses (e.g. GCNII's x_0 summands of
+        # all layers) are kept from a batch's first layer to its last when they fit: one
+        # [rows, layers * width] matrix per batch, i.e. about one more set of tables
+        keep_terms = False
+        if self.device.type == 'cuda' and not use_pool:
+            rows = sum(b[1] for b in batches)
+            need = rows * self.num_layers * self.histories[-1].embedding_dim * 4
+            keep_terms = need < 0.4 * torch.cuda.mem_get_info(self.device)[0]
 
         def ids_on_device(data, n_id):     # one upload per (static) evaluation batch
             return _ids_on(data.adj_t, n_id, self.device)
@@ -633,6 +641,7 @@ class ScalableGNN(torch.nn.Module):
             if batch_size == 0:      # padding batch of a partition-parallel run
                 continue
             adj_t = data.adj_t.to(self.device)
+            state['keep_layer_terms'] = keep_terms
             x = self._embed(data.x.to(self.device), state, batch_size)
             if with_aggregates:
                 if x.size(1) > self.histories[0].embedding_dim:

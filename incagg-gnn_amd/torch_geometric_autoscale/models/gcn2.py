@@ -67,10 +67,11 @@ class GCN2(ScalableGNN):
         gated = bool(state.get('defer_relu')) and torch.is_grad_enabled()
         state['embed_grad_gated'] = gated
         x, state['x_0'] = embed_relu(self.lins[0], x, batch_size, grad_gated=gated)
-        # Training steps (one batch, all layers back to back): the x_0 terms of every layer in
-        # one GEMM.  Not in the sweeps, where the per-batch state outlives the layer loop and
-        # the terms of all batches would have to stay resident.
-        if (self.convs[0].weight2 is not None and torch.is_grad_enabled()
+        # The x_0 terms of every layer in one GEMM: in training steps (one batch, all layers
+        # back to back) and in the sweeps whenever the terms of ALL batches fit in memory next
+        # to the tables (they stay resident from a batch's first layer to its last).
+        if (self.convs[0].weight2 is not None
+                and (torch.is_grad_enabled() or state.get('keep_layer_terms'))
                 and len({conv.alpha for conv in self.convs}) == 1):
             state['w1f'], state['x0_terms'] = gcn2_batched_terms(self.convs, state['x_0'])
         return F.dropout(x, p=self.dropout, training=self.training)
