@@ -460,6 +460,8 @@ def main():
         clock.counting = False
         bt["edges"] = clock.edges
     torch.cuda.synchronize()
+    if split_graphs and args.mode != "vr" and not model.supports_halo_ready():
+        split_graphs = False    # (e.g. a model that transforms rows before aggregating them)
     if split_graphs:
         from torch_geometric_autoscale.graphs import StepGraphs
         flat_grads = D.flatten_gradients(model)

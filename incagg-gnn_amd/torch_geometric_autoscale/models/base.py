@@ -334,6 +334,19 @@ class ScalableGNN(torch.nn.Module):
         drops = self.training and self._layer_dropout and getattr(self, "dropout", 0.0) > 0
         return not drops and history.emb.size(1) >= x.size(1)
 
+    def supports_halo_ready(self) -> bool:
+        """Whether ``model(..., halo_ready=True)`` is available: partition-parallel, every
+        layer-input table on the compute device with a tail for foreign rows, and a model whose
+        out-of-batch rows need nothing done to them before they are aggregated."""
+        if self.partition_ctx is None or not self.halo_in_place or self.pool is not None:
+            return False
+        if type(self)._pre_aggregate is not ScalableGNN._pre_aggregate:
+            return False
+        if self.training and self._layer_dropout and getattr(self, "dropout", 0.0) > 0:
+            return False
+        return all(h._base is not None and _same_device(h.emb.device, self.device)
+                   for h in self.histories[1:])
+
     def _push_and_pull_split(self, history, x: Tensor, batch_size: Optional[int],
                              n_id: Optional[Tensor], offset: Optional[Tensor],
                              count: Optional[Tensor], relu: bool = False

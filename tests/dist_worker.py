@@ -65,6 +65,27 @@ def main():
             D.allreduce_gradients(model, ctx)
             result[f"{name}/grad"] = torch.cat([p.grad.reshape(-1) for p in model.parameters()
                                                 if p.grad is not None])
+            if in_place and name == "gcn2":     # (a model that reads every layer's rows in place)
+                # the same step split at its collectives: exchanges first (foreign rows land in
+                # the table tails), then a forward that contains no collective, gradients into
+                # one flat buffer, one all-reduce of that buffer
+                flat = D.flatten_gradients(model)
+                for pending in model.start_halo_exchanges(sub.data.adj_t):
+                    pending.wait()
+                ret2 = model(sub.data.x, sub.data.adj_t, b, sub.n_id, sub.offset, sub.count,
+                             halo_ready=True)
+                assert torch.allclose(ret2["out"], ret["out"], rtol=1e-5, atol=1e-6)
+                model.zero_grad(set_to_none=False)
+                torch.nn.functional.cross_entropy(ret2["out"], sub.data.y[:b]).backward()
+                D.allreduce_flat_gradients(flat, ctx)
+                # the flat buffer holds the same all-reduced mean gradient (zeros where a
+                # parameter got no gradient, which the list of the first run leaves out)
+                n1, n2 = float(flat.norm()), float(result[f"{name}/grad"].norm())
+                assert abs(n1 - n2) <= 1e-4 * (1.0 + n2), (n1, n2)
+                assert all(p.grad.data_ptr() >= flat.data_ptr() for p in model.parameters()
+                           if p.requires_grad)
+                for p in model.parameters():
+                    p.grad = None
             # incremental-aggregation step: no halo traffic at all
             sub = D.sharded_partition_batch(data, ptr, [ctx.part_lo], ctx, in_batch_only=True)
             ret = model.VR_call(sub.data.x, sub.data.adj_t, sub.batch_size, sub.n_id, sub.offset,
