@@ -13,5 +13,8 @@ cp gpurun_out/${tag}_trace/*/*kernel_stats.csv gpurun_out/${tag}_kernel_stats.cs
 echo "pmc fetch"; timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --sweep off --epoch-pass off > gpurun_out/${tag}_fetch.log 2>&1 || exit 1
 echo "pmc write"; timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --sweep off --epoch-pass off > gpurun_out/${tag}_write.log 2>&1 || exit 1
 python3 profiles/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write 10 16 > gpurun_out/${tag}_pmc_traffic.json || exit 1
+echo "pmc l2"; timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/${tag}_l2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --sweep off --epoch-pass off > gpurun_out/${tag}_l2.log 2>&1 || exit 1
+python3 profiles/pmc_l2.py gpurun_out/${tag}_l2 10 16 > gpurun_out/${tag}_pmc_l2.json || exit 1
+rm -rf gpurun_out/${tag}_l2
 cat gpurun_out/${tag}_pmc_traffic.json
 head -12 gpurun_out/${tag}_kernel_summary.txt
