@@ -30,7 +30,7 @@ def _as_rows(x: Tensor) -> Tensor:
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_halo, add, adj, reduce, scale, add_scale, halo_ids, relu_x=False,
-                gate_grad=False):
+                gate_grad=False, grad_out=None):
         rowptr, col, val = adj.device_csr()
         n_cols = adj.size(1)
         if halo_ids is not None:
@@ -53,6 +53,7 @@ class _SpMM(torch.autograd.Function):
         ctx.halo_rows = None if x_halo is None else x_halo.size(0)
         ctx.in_place = halo_ids is not None
         ctx.has_add = add is not None
+        ctx.grad_out = grad_out
         return y
 
     @staticmethod
@@ -64,12 +65,12 @@ class _SpMM(torch.autograd.Function):
         if ctx.halo_rows is None:
             if ctx.needs_input_grad[0]:
                 dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, 0, n_cols,
-                                           ctx.x_rows, gate)
+                                           ctx.x_rows, gate, ctx.grad_out)
         else:
             # only the rows somebody needs: the pulled History rows are constants
             if ctx.needs_input_grad[0]:
                 dx = _transposed_aggregate(ctx.adj, dy, ctx.reduce, ctx.scale, 0, ctx.x_rows,
-                                           ctx.x_rows, gate)
+                                           ctx.x_rows, gate, ctx.grad_out)
             if ctx.needs_input_grad[1]:
                 if ctx.in_place:
                     raise RuntimeError("rows consumed in place from a History table are "
@@ -78,7 +79,7 @@ class _SpMM(torch.autograd.Function):
                                               n_cols, ctx.halo_rows)
         if ctx.has_add and ctx.needs_input_grad[2]:
             dadd = dy * ctx.add_scale
-        return dx, dhalo, dadd, None, None, None, None, None, None, None
+        return dx, dhalo, dadd, None, None, None, None, None, None, None, None
 
 
 class _IncAgg(torch.autograd.Function):
@@ -105,16 +106,21 @@ class _IncAgg(torch.autograd.Function):
 
 
 def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: float, lo: int,
-                          hi: int, out_rows: int, gate: Optional[Tensor] = None) -> Tensor:
+                          hi: int, out_rows: int, gate: Optional[Tensor] = None,
+                          out: Optional[Tensor] = None) -> Tensor:
     """Rows [lo, hi) of  scale * A^T dY  (A^T has one row per source row of A), padded
-    with zero rows up to ``out_rows``; ``gate`` (rows [lo, ...) of it): zeroed where <= 0."""
+    with zero rows up to ``out_rows``; ``gate`` (rows [lo, ...) of it): zeroed where <= 0.
+    ``out``: where the caller wants the result (used when its shape is the result's)."""
     t_rowptr, t_col, t_val = adj.device_csr_t(reduce)
     hi = min(hi, adj.size(1))
     if gate is not None:
         gate = gate[lo:] if lo else gate
+    if out is not None and (out_rows != hi - lo or tuple(out.shape) != (out_rows, dy.size(1))
+                            or out.dtype != dy.dtype or out.device != dy.device):
+        out = None
     # a window of row pointers addresses the same col / val arrays: no copy
     dx = ops.spmm_csr(t_rowptr[lo:hi + 1], t_col, t_val, dy, adj.size(0), "sum", scale,
-                      plan=adj.plan_t(reduce, lo, hi), gate=gate)
+                      plan=adj.plan_t(reduce, lo, hi), gate=gate, out=out)
     if out_rows > hi - lo:  # x had rows the adjacency never references
         pad = torch.zeros((out_rows - (hi - lo), dy.size(1)), dtype=dy.dtype, device=dy.device)
         dx = torch.cat([dx, pad], dim=0)
@@ -124,7 +130,8 @@ def _transposed_aggregate(adj: SparseTensor, dy: Tensor, reduce: str, scale: flo
 def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
          add: Optional[Tensor] = None, add_scale: float = 0.0,
          x_halo: Optional[Tensor] = None, halo_ids: Optional[Tensor] = None,
-         relu_x: bool = False, gate_grad: bool = False) -> Tensor:
+         relu_x: bool = False, gate_grad: bool = False,
+         grad_out: Optional[Tensor] = None) -> Tensor:
     """``adj @ x`` / ``spmm(adj, x, reduce)`` with an optional fused ``+ add_scale * add``.
 
     ``x_halo``: the source rows are ``[x ; x_halo]`` without concatenating them -- ``x``
@@ -139,7 +146,9 @@ def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
     ``relu_x``: ``x`` holds pre-activations; the call aggregates ``relu(x)`` (``x_halo`` rows
     are taken as they are) and its backward returns the gradient w.r.t. the pre-activations.
     ``gate_grad``: ``x`` is the output of a relu whose backward is folded into this call's
-    backward (the gradient returned is already zeroed where ``x <= 0``)."""
+    backward (the gradient returned is already zeroed where ``x <= 0``).
+    ``grad_out``: a [rows of x, width] buffer (rows may be strided) the backward pass writes the
+    gradient w.r.t. ``x`` into, instead of a matrix of its own."""
     if reduce not in ("sum", "add", "mean"):
         raise ValueError(f"unsupported reduce '{reduce}'")
     x = _as_rows(x)
@@ -150,7 +159,7 @@ def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
     if halo_ids is not None and x_halo is None:
         raise ValueError("halo_ids needs the table to read from (x_halo)")
     return _SpMM.apply(x, x_halo, add, adj, "mean" if reduce == "mean" else "sum", float(scale),
-                       float(add_scale), halo_ids, bool(relu_x), bool(gate_grad))
+                       float(add_scale), halo_ids, bool(relu_x), bool(gate_grad), grad_out)
 
 
 def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,

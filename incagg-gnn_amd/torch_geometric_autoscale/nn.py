@@ -190,16 +190,19 @@ class _TwoTermUpdate(torch.autograd.Function):
 
 class _X0Terms(torch.autograd.Function):
     """``x_0 @ [W_1 | ... | W_L]`` handed out as the L column blocks ``[rows, C]`` of ONE
-    ``[rows, L*C]`` matrix; the backward pass concatenates the blocks' gradients once and runs
-    two wide GEMMs on them."""
+    ``[rows, L*C]`` matrix.  ``grad_stack``: a matrix of that shape whose column blocks the
+    producers of the blocks' gradients may have written in place (see
+    :func:`~torch_geometric_autoscale.aggregate.spmm`, ``grad_out``); gradients that arrive
+    elsewhere are copied into their block, and the two wide backward GEMMs run on the stack
+    without concatenating anything."""
 
     @staticmethod
-    def forward(ctx, x_0, wcat, n_layers):
+    def forward(ctx, x_0, wcat, n_layers, grad_stack):
         # (row pitch: the blocks become layer outputs, which the next aggregation gathers from)
         buf = _mm_rows(x_0, wcat)
         c = wcat.size(1) // n_layers
         ctx.save_for_backward(x_0, wcat)
-        ctx.c = c
+        ctx.grad_stack, ctx.c = grad_stack, c
         # .data: a version counter per block.  The blocks never overlap and every consumer
         # updates its own one in place; with the counter of `buf` shared among them, what
         # another consumer saved of ITS block would count as modified.
@@ -208,11 +211,21 @@ class _X0Terms(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dterms):
         x_0, wcat = ctx.saved_tensors
+        c, stack = ctx.c, ctx.grad_stack
         rows = x_0.size(0)
-        d = torch.cat([x_0.new_zeros(rows, ctx.c) if g is None else g for g in dterms], dim=1)
+        if stack is not None and tuple(stack.shape) == (rows, c * len(dterms)):
+            for i, g in enumerate(dterms):
+                blk = stack[:, i * c:(i + 1) * c]
+                if g is None:
+                    blk.zero_()
+                elif g.data_ptr() != blk.data_ptr() or g.stride() != blk.stride():
+                    blk.copy_(g)
+            d = stack
+        else:
+            d = torch.cat([x_0.new_zeros(rows, c) if g is None else g for g in dterms], dim=1)
         dx0 = d @ wcat.t() if ctx.needs_input_grad[0] else None
         dw = _tn_product(x_0, d) if ctx.needs_input_grad[1] else None
-        return dx0, dw, None
+        return dx0, dw, None, None
 
 
 class RowsLinear(Linear):
@@ -352,7 +365,7 @@ class GCN2Conv(torch.nn.Module):
         return self.forward_after_propagate(spmm(adj_t, x), x_0)
 
 
-def gcn2_batched_terms(convs, x_0: Tensor):
+def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
     """For GCNII layers with separate weights: the folded first weights of ALL layers (a tuple
     of L ``[C, C]`` matrices) and the ``x_0`` summands of all layers, a tuple of L ``[rows, C]``
     matrices cut from ONE ``[rows, C] x [C, L*C]`` product -- ``x_0`` is the same matrix in
@@ -361,7 +374,7 @@ def gcn2_batched_terms(convs, x_0: Tensor):
     Folding ``scale * (beta W + (1 - beta) I)`` is one fused multiply-add per weight set over
     constants built once; the folded first weights are handed out with ``unbind`` so that their
     gradients come back as one stack instead of L zero-fill + copy + add rounds, the ``x_0``
-    summands by :class:`_X0Terms`."""
+    summands by :class:`_X0Terms` (``grad_stack``: see there)."""
     n_layers, c = len(convs), convs[0].channels
     dev, dt = x_0.device, x_0.dtype
     alpha = convs[0].alpha
@@ -379,7 +392,7 @@ def gcn2_batched_terms(convs, x_0: Tensor):
     c1, b1, c2cat, b2cat = consts[key]
     w1f = torch.addcmul(c1, torch.stack([conv.weight1 for conv in convs]), b1)
     w2cat = torch.addcmul(c2cat, torch.cat([conv.weight2 for conv in convs], dim=1), b2cat)
-    return w1f.unbind(0), _X0Terms.apply(x_0, w2cat, n_layers)
+    return w1f.unbind(0), _X0Terms.apply(x_0, w2cat, n_layers, grad_stack)
 
 
 class SAGEConv(torch.nn.Module):
