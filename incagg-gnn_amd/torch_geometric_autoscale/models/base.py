@@ -482,6 +482,10 @@ class ScalableGNN(torch.nn.Module):
                 xa = self._pre_aggregate(i, x)
                 fuse = dict(relu_x=relu_pending,
                             gate_grad=i == 0 and state.get('embed_grad_gated', False))
+                if relu_pending and 'grad_blocks' in state:
+                    # x is the previous layer's output itself: its gradient is this
+                    # aggregation's input gradient, written where the model wants it
+                    fuse['grad_out'] = state['grad_blocks'][i - 1]
                 if mix is not None:
                     agg = spmm(adj, x, self.agg_reduce, *mix, x_halo=halo, halo_ids=halo_ids,
                                **fuse)

@@ -7,6 +7,7 @@ from torch.nn import BatchNorm1d, ModuleList
 
 import torch
 
+from .. import ops
 from ..nn import GCN2Conv, RowsLinear, embed_relu, gcn2_batched_terms
 from .base import ScalableGNN
 
@@ -73,7 +74,16 @@ class GCN2(ScalableGNN):
         if (self.convs[0].weight2 is not None
                 and (torch.is_grad_enabled() or state.get('keep_layer_terms'))
                 and len({conv.alpha for conv in self.convs}) == 1):
-            state['w1f'], state['x0_terms'] = gcn2_batched_terms(self.convs, state['x_0'])
+            stack = None
+            if state.get('defer_relu') and torch.is_grad_enabled():
+                # gradients of the layer outputs land side by side (the next layer's aggregation
+                # writes its input gradient straight into block `layer`): the backward GEMMs of
+                # the x_0 terms then need no concatenation
+                c = self.convs[0].channels
+                stack = ops.rows_empty(batch_size, c * self.num_layers, x.device, x.dtype)
+                state['grad_blocks'] = [stack[:, i * c:(i + 1) * c]
+                                        for i in range(self.num_layers)]
+            state['w1f'], state['x0_terms'] = gcn2_batched_terms(self.convs, state['x_0'], stack)
         return F.dropout(x, p=self.dropout, training=self.training)
 
     def _post(self, layer: int, h: Tensor, x: Tensor, state: Dict[str, Any] = None) -> Tensor:

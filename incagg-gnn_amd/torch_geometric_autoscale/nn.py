@@ -31,15 +31,11 @@ def _mm_rows(a: Tensor, b: Tensor) -> Tensor:
 
 def _slab_count(rows: int) -> int:
     """Number of row slabs for :func:`_tn_product`.  hipBLASLt's choice of kernel for the
-    batched product swings with the count (16k rows x 256 x 256 on MI355X: 46-51 us with 6, 8
-    or 9 slabs, 140-250 us with 16 to 32; 128k rows x 256 x 100: 72-77 us with 16, 32 or 64,
-    116 us with 8), so only counts measured to be good are used, preferring one that divides
-    ``rows`` (no remainder rows, i.e. no extra tiny GEMM)."""
-    good = (8, 9, 6) if rows < 65536 else (32, 64, 16)
-    for s in good:
-        if rows % s == 0:
-            return s
-    return good[0]
+    batched product swings with the count (16k rows x 256 x 256 on MI355X, product alone: 26 us
+    with 8 slabs, 42-44 us with 6 or 9, 140-250 us with 16 to 32; 128k rows x 256 x 100: 72-77
+    us with 16, 32 or 64, 116 us with 8), so only the best measured counts are used; rows that
+    do not fill a slab go to the finishing kernel."""
+    return 8 if rows < 65536 else 32
 
 
 def _tn_product(a: Tensor, b: Tensor) -> Tensor:
