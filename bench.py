@@ -393,13 +393,41 @@ def main():
     split_graphs = sharded and args.graphs != "off" and not host_tables
     if split_graphs:
         use_graphs = False
-    # one launch per step; capturable: the step counter lives on the device
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graphs)
+    # Partition-parallel split steps: the trainable parameters live in ONE flat tensor (every
+    # parameter of the model is a view of it) and the optimizer is given that one tensor with
+    # the concatenated gradient -- the buffer the all-reduce works on.  Adam is element-wise:
+    # the update is the same as over the parameter list.  Single-GPU steps keep the parameter
+    # list (measured: no faster with the flat form there).
+    # capturable: the step counter lives on the device.
+    train_params = [p_ for p_ in model.parameters() if p_.requires_grad]
+    # (every parameter starts 256-byte aligned inside the flat tensor: GEMM operands)
+    sizes = [-(-p_.numel() // 64) * 64 for p_ in train_params]
+    flat_w = torch.nn.Parameter(torch.zeros(sum(sizes), device=dev))
+    off = 0
+    for p_, n_ in zip(train_params, sizes):
+        flat_w.data[off:off + p_.numel()] = p_.detach().reshape(-1)
+        p_.data = flat_w.data[off:off + p_.numel()].view_as(p_)
+        off += n_
+    no_grad_yet = [torch.zeros(n_, device=dev) for n_ in sizes]   # (never written)
+
+    def padded(g, n_):      # a gradient, zero-extended to its parameter's slot
+        g = g.reshape(-1)
+        return g if g.numel() == n_ else torch.nn.functional.pad(g, (0, n_ - g.numel()))
+    opt_flat = torch.optim.Adam([flat_w], lr=1e-3, fused=True)
+    opt = torch.optim.Adam(train_params, lr=1e-3, fused=True, capturable=use_graphs)
     crit = torch.nn.CrossEntropyLoss()
     model.train()
     setup_s = time.perf_counter() - t_setup
 
-    flat_grads = None
+    def clear_grads():
+        for p_ in train_params:
+            p_.grad = None
+
+    def gathered_grads():
+        return torch.cat([z if p_.grad is None else padded(p_.grad, z.numel())
+                          for p_, z in zip(train_params, no_grad_yet)])
+
+    flat_grads = None       # partition-parallel split steps: {batch: its recorded gradient}
 
     def step(i):
         k = i % len(batches)
@@ -418,8 +446,9 @@ def main():
         else:
             out = model(bt["x"], bt["adj"], bt["b"], bt["nid_dev"], bt["offset"], bt["count"],
                         halo_ready=True)["out"]
-        opt.zero_grad(set_to_none=False)    # gradients are views of one flat buffer
+        clear_grads()
         crit(out, bt["y"]).backward()
+        return gathered_grads()
 
     def split_step(k, replay):
         bt = batches[k]
@@ -428,10 +457,12 @@ def main():
                 pending.wait()
         if replay:
             graphs.replay(k)
+            grad = flat_grads[k]    # (recorded: the same memory in every replay)
         else:
-            split_body(k)
-        D.allreduce_flat_gradients(flat_grads, ctx)
-        opt.step()
+            grad = split_body(k)
+        D.allreduce_flat_gradients(grad, ctx)
+        flat_w.grad = grad
+        opt_flat.step()
         return bt["edges"]
 
     def eager_step(k):
@@ -464,7 +495,7 @@ def main():
         split_graphs = False    # (e.g. a model that transforms rows before aggregating them)
     if split_graphs:
         from torch_geometric_autoscale.graphs import StepGraphs
-        flat_grads = D.flatten_gradients(model)
+        flat_grads = {}
         graphs = StepGraphs(dev)
         for k in range(len(batches)):
             graphs.warm(lambda: split_step(k, replay=False), times=1)
@@ -472,7 +503,8 @@ def main():
         recorded = True
         try:
             for k in range(len(batches)):
-                graphs.capture(k, lambda: split_body(k), capture_error_mode="thread_local")
+                graphs.capture(k, lambda: flat_grads.__setitem__(k, split_body(k)),
+                               capture_error_mode="thread_local")
             torch.cuda.synchronize()
         except Exception as exc:     # fall back to eagerly issued steps, on every rank alike
             print(f"rank {rank}: recording the step failed ({exc!r}); steps are issued eagerly",
@@ -482,8 +514,7 @@ def main():
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         if not int(agreed):
             graphs = flat_grads = None
-            for p_ in model.parameters():
-                p_.grad = None
+            clear_grads()
     if use_graphs:
         # every batch's step is recorded once (untimed) and replayed from then on
         from torch_geometric_autoscale.graphs import StepGraphs
