@@ -83,7 +83,8 @@ class GCN2(ScalableGNN):
                 stack = ops.rows_empty(batch_size, c * self.num_layers, x.device, x.dtype)
                 state['grad_blocks'] = [stack[:, i * c:(i + 1) * c]
                                         for i in range(self.num_layers)]
-            state['w1f'], state['x0_terms'] = gcn2_batched_terms(self.convs, state['x_0'], stack)
+            state['w1f'], state['x0_terms'], state['dw1'] = gcn2_batched_terms(
+                self.convs, state['x_0'], stack)
         return F.dropout(x, p=self.dropout, training=self.training)
 
     def _post(self, layer: int, h: Tensor, x: Tensor, state: Dict[str, Any] = None) -> Tensor:
@@ -104,7 +105,8 @@ class GCN2(ScalableGNN):
                 pre: bool = False) -> Tensor:
         if 'x0_terms' in state:
             h = self.convs[layer].forward_after_propagate(
-                agg, state['x_0'], state['w1f'][layer], state['x0_terms'][layer])
+                agg, state['x_0'], state['w1f'][layer], state['x0_terms'][layer],
+                None if state.get('dw1') is None else state['dw1'][layer])
         else:
             h = self.convs[layer].forward_after_propagate(agg, state['x_0'])
         return self._post(layer, h, x, state)

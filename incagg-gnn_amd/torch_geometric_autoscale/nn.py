@@ -38,7 +38,7 @@ def _slab_count(rows: int) -> int:
     return 8 if rows < 65536 else 32
 
 
-def _tn_product(a: Tensor, b: Tensor) -> Tensor:
+def _tn_product(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """``a^T @ b`` for tall operands ([rows, m], [rows, n], rows >> m, n): the shape of every
     weight gradient here.  A [m, n] output gives a GEMM only a handful of tiles while the
     reduction runs over 10^4..10^5 rows, so the rows are cut into slabs that run as one
@@ -47,6 +47,8 @@ def _tn_product(a: Tensor, b: Tensor) -> Tensor:
     77 us with 32 slabs, 123 us with 8, 376 us as one GEMM.  Rows may be strided (slices of a
     wider matrix): nothing is copied."""
     rows = a.size(0)
+    if out is not None and not (a.is_cuda and a.dtype == torch.float32 and rows >= 4096):
+        out = None          # (only the finishing kernel writes where it is told to)
     if rows < 4096 or a.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
         return a.t() @ b
     slabs = _slab_count(rows)
@@ -59,7 +61,7 @@ def _tn_product(a: Tensor, b: Tensor) -> Tensor:
             out.addmm_(a[k:].t(), b[k:])
         return out
     # slab sum and remainder rows in one launch (a GEMM over < 10 rows costs a full launch)
-    return ops.tn_finish(parts, a[k:] if k < rows else None, b[k:] if k < rows else None)
+    return ops.tn_finish(parts, a[k:] if k < rows else None, b[k:] if k < rows else None, out)
 
 
 def _column_sums(x: Tensor) -> Tensor:
@@ -159,9 +161,10 @@ class _TwoTermUpdate(torch.autograd.Function):
     result."""
 
     @staticmethod
-    def forward(ctx, h, w1, x0, w2, term=None):
+    def forward(ctx, h, w1, x0, w2, term=None, dw1_out=None):
         ctx.save_for_backward(h, w1, x0, w2)
         ctx.has_term = term is not None
+        ctx.dw1_out = dw1_out       # where the caller wants the gradient of w1 (may be ignored)
         if term is not None:
             ctx.mark_dirty(term)
             return term.addmm_(h, w1)
@@ -175,13 +178,34 @@ class _TwoTermUpdate(torch.autograd.Function):
         if dy.stride(-1) != 1:
             dy = dy.contiguous()
         dh = _mm_rows(dy, w1.t()) if ctx.needs_input_grad[0] else None
-        dw1 = _tn_product(h, dy) if ctx.needs_input_grad[1] else None
+        dw1 = _tn_product(h, dy, ctx.dw1_out) if ctx.needs_input_grad[1] else None
         dx0 = dw2 = None
         if x0 is not None:
             dx0 = dy @ w2.t() if ctx.needs_input_grad[2] else None
             dw2 = _tn_product(x0, dy) if ctx.needs_input_grad[3] else None
         dterm = dy if ctx.has_term and ctx.needs_input_grad[4] else None
-        return dh, dw1, dx0, dw2, dterm
+        return dh, dw1, dx0, dw2, dterm, None
+
+
+class _Layers(torch.autograd.Function):
+    """``stack.unbind(0)`` whose backward takes the gradients of the pieces where they are when
+    their producers wrote them into ``grad_stack`` (a ``[L, ...]`` matrix, piece l in
+    ``grad_stack[l]``) instead of copying every one of them into a fresh stack."""
+
+    @staticmethod
+    def forward(ctx, stack, grad_stack):
+        ctx.grad_stack = grad_stack
+        return tuple(t.data for t in stack.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = ctx.grad_stack
+        for i, g in enumerate(grads):
+            if g is None:
+                gs[i].zero_()
+            elif g.data_ptr() != gs[i].data_ptr() or g.stride() != gs[i].stride():
+                gs[i].copy_(g)
+        return gs, None
 
 
 class _X0Terms(torch.autograd.Function):
@@ -330,13 +354,14 @@ class GCN2Conv(torch.nn.Module):
         return out
 
     def forward_after_propagate(self, h: Tensor, x_0: Tensor, w1_folded: Optional[Tensor] = None,
-                                x0_term: Optional[Tensor] = None) -> Tensor:
+                                x0_term: Optional[Tensor] = None,
+                                dw1_out: Optional[Tensor] = None) -> Tensor:
         """Everything after the propagation, given ``h = A x`` (models/gcn2.py:257,306).
         ``w1_folded`` / ``x0_term``: this layer's slice of :func:`gcn2_batched_terms`, computed
         for all layers at once by the caller."""
         b = h.size(0)
         if x0_term is not None:
-            return _TwoTermUpdate.apply(h, w1_folded, None, None, x0_term)
+            return _TwoTermUpdate.apply(h, w1_folded, None, None, x0_term, dw1_out)
         x_0 = x_0 if x_0.size(0) == b else x_0[:b]
         if self.weight2 is None:
             p = torch.add(h * (1 - self.alpha), x_0, alpha=self.alpha)
@@ -370,7 +395,9 @@ def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
     Folding ``scale * (beta W + (1 - beta) I)`` is one fused multiply-add per weight set over
     constants built once; the folded first weights are handed out with ``unbind`` so that their
     gradients come back as one stack instead of L zero-fill + copy + add rounds, the ``x_0``
-    summands by :class:`_X0Terms` (``grad_stack``: see there)."""
+    summands by :class:`_X0Terms` (``grad_stack``: see there).  Third result: where the layers
+    may leave the gradients of their folded weights (``forward_after_propagate``'s ``dw1_out``),
+    or ``None`` outside training."""
     n_layers, c = len(convs), convs[0].channels
     dev, dt = x_0.device, x_0.dtype
     alpha = convs[0].alpha
@@ -388,7 +415,12 @@ def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
     c1, b1, c2cat, b2cat = consts[key]
     w1f = torch.addcmul(c1, torch.stack([conv.weight1 for conv in convs]), b1)
     w2cat = torch.addcmul(c2cat, torch.cat([conv.weight2 for conv in convs], dim=1), b2cat)
-    return w1f.unbind(0), _X0Terms.apply(x_0, w2cat, n_layers, grad_stack)
+    terms = _X0Terms.apply(x_0, w2cat, n_layers, grad_stack)
+    if not (torch.is_grad_enabled() and w1f.requires_grad):
+        return w1f.unbind(0), terms, None
+    # the layers' weight gradients are written side by side by their producers
+    dw1 = torch.empty_like(w1f)
+    return _Layers.apply(w1f, dw1), terms, dw1.unbind(0)
 
 
 class SAGEConv(torch.nn.Module):

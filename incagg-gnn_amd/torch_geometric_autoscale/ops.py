@@ -345,9 +345,11 @@ def rows_sub(a: Tensor, b: Tensor) -> Tensor:
     return out
 
 
-def tn_finish(parts: Tensor, a_tail: Optional[Tensor], b_tail: Optional[Tensor]) -> Tensor:
+def tn_finish(parts: Tensor, a_tail: Optional[Tensor], b_tail: Optional[Tensor],
+              out: Optional[Tensor] = None) -> Tensor:
     """``parts.sum(0) + a_tail^T @ b_tail`` (incagg_tn_finish_f32): the slab sum of a batched
-    weight-gradient product and its few remainder rows in one launch."""
+    weight-gradient product and its few remainder rows in one launch; into ``out`` (contiguous
+    ``[m, n]``) when given."""
     _need_cuda(parts, "parts")
     if parts.dim() != 3 or parts.dtype != torch.float32 or not parts.is_contiguous():
         raise ValueError("parts must be a contiguous [slabs, m, n] float32 tensor")
@@ -359,7 +361,11 @@ def tn_finish(parts: Tensor, a_tail: Optional[Tensor], b_tail: Optional[Tensor])
         r = a_tail.size(0)
         if b_tail.size(0) != r or a_tail.size(1) != m or b_tail.size(1) != n:
             raise ValueError("remainder rows must be [r, m] and [r, n]")
-    out = torch.empty((m, n), dtype=torch.float32, device=parts.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=parts.device)
+    elif (tuple(out.shape) != (m, n) or out.dtype != torch.float32 or not out.is_contiguous()
+          or out.device != parts.device):
+        raise ValueError("out must be a contiguous [m, n] float32 tensor on the device of parts")
     with _on_device(parts.device):
         check(lib().incagg_tn_finish_f32(
             _ptr(parts), s_, _ptr(a_tail) if r else None, _ld(a_tail) if r else 0,

@@ -206,8 +206,8 @@ def test_batched_gcn2_terms_and_fused_embed_have_the_plain_gradients():
     def run(fast):
         if fast:
             full, x0 = embed_relu(lin, x, b)
-            w1f, terms = gcn2_batched_terms(convs, x0)
-            outs = [conv.forward_after_propagate(a, x0, w1f[i], terms[i])
+            w1f, terms, dw1 = gcn2_batched_terms(convs, x0)
+            outs = [conv.forward_after_propagate(a, x0, w1f[i], terms[i], dw1[i])
                     for i, (conv, a) in enumerate(zip(convs, aggs))]
         else:
             full = lin(x).relu()
