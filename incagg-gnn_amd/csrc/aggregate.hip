@@ -505,16 +505,54 @@ __device__ __forceinline__ int group_max8(int v) {  // max over the 8 lane group
   return v;
 }
 
+// Runs of kRun = 128 consecutive positions of [0, n) dealt out to `groups` classes in turn, the class
+// of element i being (i + off) % groups: element i takes position regroup(i), so that the
+// elements of one class walk through runs j, j + groups, j + 2 groups, ... in ascending order.
+// (A bijection of [0, n): positions past the last whole round of groups * kRun stay put.)
+// Scalar work.
+constexpr int kRun = 128;
+__device__ __forceinline__ int regroup(int i, int n, int groups, int off) {
+  const int round = groups * kRun;
+  if (i >= n - n % round) return i;
+  const int j = (i + off) % groups, rank = i / groups;
+  return ((rank / kRun) * groups + j) * kRun + rank % kRun;
+}
+
+// Position of element i of [0, n) when the elements are laid out class after class instead (the
+// class of i being i % groups), in ascending order inside a class: every class takes ONE
+// contiguous range.  Scalar work.
+__device__ __forceinline__ int regroup_ranges(int i, int n, int groups) {
+  const int j = i % groups;
+  // classes below j: those below n % groups hold one element more
+  return j * (n / groups) + min(j, n % groups) + i / groups;
+}
+
+// groups > 1 (narrow matrices: 1, 2 or 4 slices, so that 8 / n_slices workgroups in a row land
+// on different XCDs): workgroup v takes the work of position regroup(v), i.e. the workgroups of
+// one XCD (pair, quad) take one contiguous range of the plan's items and whole runs of 128 x 32
+// consecutive short rows.  With a plan ordered chunk by chunk a run is about four chunks of
+// 1,024 rows: their source rows -- mostly rows of the same chunks -- are fetched into ONE
+// private L2, and the runs of an XCD alternate between all parts of the matrix (even work per
+// XCD also where the rows of one part are much longer than those of another, e.g. the in-batch
+// and the out-of-batch rows of a transposed batch adjacency; items are of similar length
+// everywhere).  Measured, reddit-sized batch (116 k rows, 11.9 M edges) at width 41, us per
+// launch, forward / transposed [M,B] / transposed [B,B]: plan by length only 494 / 446 / 393;
+// chunked plan, contiguous ranges for items and rows 258 / 296 / 198; runs of 32 for both
+// 282 / 253 / 207; ranges for items + runs of 32 269 / 261 / 200, + runs of 128 257 / 248 / 197.
 // (second launch bound: waves per SIMD the register allocation must leave room for)
 template <bool INCAGG, int WIDE, bool ODD>
 __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_plan_kernel(
-    const SpmmArgs a, int n_slices) {
+    const SpmmArgs a, int n_slices, int groups) {
   __shared__ f4 part[kWavesPerBlock][8];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 3, t = lane & 7;
   const int slice = blockIdx.x % n_slices;
-  const int vb = blockIdx.x / n_slices;
+  int vb = blockIdx.x / n_slices;
+  if (groups > 1)
+    vb = vb < a.n_items ? regroup_ranges(vb, a.n_items, groups)
+                        : a.n_items + regroup(vb - a.n_items, (int)(gridDim.x / n_slices) - a.n_items,
+                                              groups, a.n_items);
   const int col0 = slice * kSliceFloats + t * 4;
   const bool live = col0 < a.width;
   // (width >= 4.)  A row's last piece ends with the row: when the width is not a multiple of 4
@@ -718,6 +756,9 @@ struct Tuning {
   int hub_threshold = env_int("INCAGG_HUB_THRESHOLD", 128);
   int segment_edges = env_int("INCAGG_SEGMENT_EDGES", 4096);
   int wide_addressing = env_int("INCAGG_WIDE_ADDRESSING", -1);  // 1: never the 24-bit form
+  // matrices of more rows than plan_local_rows get a chunk-by-chunk row order (spmm_plan.hip)
+  int plan_local_rows = env_int("INCAGG_PLAN_LOCAL_ROWS", 32768);
+  int plan_chunk_rows = env_int("INCAGG_PLAN_CHUNK_ROWS", 1024);
 };
 static Tuning &tuning() {
   static Tuning t;
@@ -727,6 +768,11 @@ static Tuning &tuning() {
 void plan_defaults(int *hub_threshold, int *segment_edges) {
   *hub_threshold = std::max(1, tuning().hub_threshold);
   *segment_edges = std::max(kWave, (tuning().segment_edges + kWave - 1) / kWave * kWave);
+}
+
+int plan_chunk_rows(long long n_rows) {
+  const Tuning &t = tuning();
+  return t.plan_chunk_rows > 0 && n_rows > t.plan_local_rows ? t.plan_chunk_rows : 0;
 }
 
 static int bind_plan(SpmmArgs &a, const incagg_spmm_plan *plan) {
@@ -813,8 +859,11 @@ static int launch_sliced(SpmmArgs &a, const incagg_spmm_plan *plan, hipStream_t 
                       a.ldb2 < (1u << 24) && (long long)a.split * a.ldb1 < (1ll << 32) &&
                       rows2 * a.ldb2 < (1ll << 32);
   const bool odd = a.width % 4 != 0;
+  // (a plan ordered chunk by chunk: see the kernel)
+  const int groups = plan && plan_chunk_rows(a.n_rows) > 0 && (n_slices == 1 || n_slices == 2 || n_slices == 4)
+                         ? 8 / n_slices : 1;
 #define INCAGG_LAUNCH_PLAN(W, O) \
-  hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, W, O>), grid, block, 0, stream, a, n_slices)
+  hipLaunchKernelGGL((spmm_plan_kernel<INCAGG, W, O>), grid, block, 0, stream, a, n_slices, groups)
   if (fast24 && odd) INCAGG_LAUNCH_PLAN(2, true);
   else if (fast24) INCAGG_LAUNCH_PLAN(2, false);
   else if (wide && odd) INCAGG_LAUNCH_PLAN(1, true);
@@ -954,6 +1003,8 @@ extern "C" int incagg_set_tuning(const char *key, int value) {
   else if (k == "hub_threshold") t.hub_threshold = value;
   else if (k == "segment_edges") t.segment_edges = value;
   else if (k == "wide_addressing") t.wide_addressing = value;
+  else if (k == "plan_local_rows") t.plan_local_rows = value;
+  else if (k == "plan_chunk_rows") t.plan_chunk_rows = value;
   else return fail(INCAGG_E_INVALID, "unknown tuning key '%s'", key);
   return INCAGG_OK;
 }

@@ -31,6 +31,9 @@ int error_flag_address(int **out);
 
 // Defaults of the aggregation plan builders (tunable, see incagg_set_tuning).
 void plan_defaults(int *hub_threshold, int *segment_edges);
+// Rows per chunk of the plan's row order for a matrix of n_rows rows; 0: one descending-length
+// order over all rows (see spmm_plan.hip).
+int plan_chunk_rows(long long n_rows);
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

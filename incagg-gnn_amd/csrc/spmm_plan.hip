@@ -2,8 +2,18 @@
 // (and once per window of a transposed adjacency) at batch construction, on the host or on the
 // GPU.  Integer work; both builders produce the same arrays, element for element.
 //
-//   order[n_rows]      rows by descending length, ties in ascending row id (stable)
-//   n_hub              rows longer than hub_threshold: the first n_hub entries of `order`
+//   order[n_rows]      the rows longer than hub_threshold first (n_hub of them), then the others;
+//                      in both parts by descending length, ties in ascending row id (stable).
+//                      Matrices of more than plan_local_rows rows (32,768) are ordered chunk by
+//                      chunk instead: inside both parts the rows of chunk 0 (row ids 0..1023)
+//                      come first, then chunk 1, ..., each chunk by descending length.  Rows of a
+//                      batch are its partitions one after another and most edges stay inside a
+//                      partition: rows processed at about the same time then gather from the same
+//                      few thousand source rows, which a 4 MiB L2 holds (measured on a reddit-
+//                      sized batch of 116 k rows at width 41: 494 -> 291 us per launch; 257 us
+//                      with the sliced kernel's per-XCD runs of workgroups).  Below that size
+//                      a slice of all in-batch source rows fits the L2 anyway and chunks only
+//                      cost balance (products batch, 16 k rows, width 256: 58 -> 65 us).
 //   items[2 * n_items] (row, segment) pairs, rows in the order above, segments ascending;
 //                      a segment is segment_edges edges (the last one shorter)
 //   multi_rows[n_multi] the rows with more than one segment
@@ -31,8 +41,20 @@ struct PlanStatus {
   int error;  // 1: negative row length, 2: capacity exceeded
 };
 
-__global__ __launch_bounds__(kBlock) void plan_degrees_kernel(const int *rowptr, int n_rows,
-                                                             int *deg, int *ids, PlanStatus *st) {
+// Sort key of a row (ascending, stable): short rows after long ones, then the chunk of the row,
+// then descending length.
+typedef unsigned long long PlanKey;
+constexpr int kPlanKeyBits = 63;
+__host__ __device__ inline PlanKey plan_key(int row, int d, int hub_threshold, int chunk_rows) {
+  return (d > hub_threshold ? 0ull : 1ull << 62) |
+         ((PlanKey)(chunk_rows > 0 ? row / chunk_rows : 0) << 31) | (PlanKey)(0x7fffffff - d);
+}
+__host__ __device__ inline int key_length(PlanKey k) { return 0x7fffffff - (int)(k & 0x7fffffffull); }
+__host__ __device__ inline bool key_long(PlanKey k) { return (k >> 62) == 0; }
+
+__global__ __launch_bounds__(kBlock) void plan_keys_kernel(const int *rowptr, int n_rows,
+                                                          int hub_threshold, int chunk_rows,
+                                                          PlanKey *keys, int *ids, PlanStatus *st) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_rows) return;
   int d = rowptr[i + 1] - rowptr[i];
@@ -40,26 +62,25 @@ __global__ __launch_bounds__(kBlock) void plan_degrees_kernel(const int *rowptr,
     st->error = 1;
     d = 0;
   }
-  deg[i] = d;
+  keys[i] = plan_key(i, d, hub_threshold, chunk_rows);
   ids[i] = i;
 }
 
 // Over the sorted positions: segments and "several segments" flag of every position.
-__global__ __launch_bounds__(kBlock) void plan_segments_kernel(const int *deg_sorted, int n_rows,
-                                                              int hub_threshold, int seg,
-                                                              int *nseg, int *multi) {
+__global__ __launch_bounds__(kBlock) void plan_segments_kernel(const PlanKey *sorted, int n_rows,
+                                                              int seg, int *nseg, int *multi) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= n_rows) return;
-  const int d = deg_sorted[j];
-  const int k = d > hub_threshold ? (d + seg - 1) / seg : 0;
+  const int d = key_length(sorted[j]);
+  const int k = key_long(sorted[j]) ? (d + seg - 1) / seg : 0;
   nseg[j] = k;
   multi[j] = k > 1 ? 1 : 0;
 }
 
-__global__ __launch_bounds__(kBlock) void plan_fill_kernel(const int *order, const int *deg_sorted,
+__global__ __launch_bounds__(kBlock) void plan_fill_kernel(const int *order, const PlanKey *sorted,
                                                           const int *nseg, const int *item_off,
                                                           const int *multi_off, int n_rows,
-                                                          int hub_threshold, long long items_cap,
+                                                          long long items_cap,
                                                           long long multi_cap, int2 *items,
                                                           int *multi_rows, PlanStatus *st) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
@@ -69,10 +90,8 @@ __global__ __launch_bounds__(kBlock) void plan_fill_kernel(const int *order, con
     st->n_items = item_off[j] + k;
     st->n_multi = multi_off[j] + (k > 1 ? 1 : 0);
   }
-  // sorted descending: the long rows are a prefix, its length is the first position whose
-  // successor (or itself) is short
-  if (deg_sorted[j] > hub_threshold && (j == n_rows - 1 || deg_sorted[j + 1] <= hub_threshold))
-    st->n_hub = j + 1;
+  // the long rows are a prefix: it ends at the last long position
+  if (key_long(sorted[j]) && (j == n_rows - 1 || !key_long(sorted[j + 1]))) st->n_hub = j + 1;
   if (k == 0) return;
   const int row = order[j];
   const long long base = item_off[j];
@@ -112,6 +131,8 @@ extern "C" int incagg_spmm_plan_defaults(int32_t *hub_threshold, int32_t *segmen
   return INCAGG_OK;
 }
 
+extern "C" int32_t incagg_spmm_plan_chunk_rows(int64_t n_rows) { return plan_chunk_rows(n_rows); }
+
 extern "C" int64_t incagg_spmm_plan_items_bound(int64_t n_rows, int64_t nnz, int32_t hub_threshold,
                                                 int32_t segment_edges) {
   if (n_rows < 0 || nnz < 0) return fail(INCAGG_E_INVALID, "negative size");
@@ -136,9 +157,11 @@ extern "C" int incagg_spmm_plan_host(const int32_t *rowptr, int64_t n_rows, int3
   INCAGG_REQUIRE(rowptr && order, "null rowptr or order");
   for (int64_t i = 0; i < n_rows; i++)
     if (rowptr[i + 1] < rowptr[i]) return fail(INCAGG_E_INVALID, "row pointers decrease at row %lld", (long long)i);
+  const int chunk_rows = plan_chunk_rows(n_rows);
   std::iota(order, order + n_rows, 0);
   std::stable_sort(order, order + n_rows, [&](int32_t a, int32_t b) {
-    return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b];
+    return plan_key(a, rowptr[a + 1] - rowptr[a], hub_threshold, chunk_rows) <
+           plan_key(b, rowptr[b + 1] - rowptr[b], hub_threshold, chunk_rows);
   });
   int64_t n_hub = 0, n_items = 0, n_multi = 0;
   for (int64_t j = 0; j < n_rows; j++) {
@@ -170,11 +193,11 @@ extern "C" int64_t incagg_spmm_plan_device_scratch_bytes(int64_t n_rows) {
   if (n_rows < 0 || n_rows >= INT_MAX - 64) return fail(INCAGG_E_INVALID, "row count out of range");
   const int n = (int)std::max<int64_t>(n_rows, 1);
   size_t sort = 0, scan = 0;
-  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort, (int *)nullptr, (int *)nullptr,
-                                                     (int *)nullptr, (int *)nullptr, n);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort, (PlanKey *)nullptr, (PlanKey *)nullptr,
+                                           (int *)nullptr, (int *)nullptr, n, 0, kPlanKeyBits);
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (int *)nullptr, (int *)nullptr, n);
-  return (int64_t)(up256(sizeof(PlanStatus)) + 7 * up256(sizeof(int) * (size_t)n) +
-                   up256(std::max(sort, scan)));
+  return (int64_t)(up256(sizeof(PlanStatus)) + 2 * up256(sizeof(PlanKey) * (size_t)n) +
+                   5 * up256(sizeof(int) * (size_t)n) + up256(std::max(sort, scan)));
 }
 
 // Enqueues the device builder; the counts stay in *status_out (device memory inside scratch).
@@ -184,36 +207,38 @@ static int plan_device_enqueue(const int32_t *rowptr, int n, int32_t hub_thresho
                                int32_t *multi_rows, int64_t multi_cap, PlanStatus **status_out,
                                hipStream_t stream) {
   char *base = static_cast<char *>(scratch);
-  const size_t e = up256(sizeof(int) * (size_t)n);
+  const size_t e = up256(sizeof(int) * (size_t)n), k = up256(sizeof(PlanKey) * (size_t)n);
   PlanStatus *st = reinterpret_cast<PlanStatus *>(base);
   base += up256(sizeof(PlanStatus));
-  int *deg = reinterpret_cast<int *>(base);
-  int *ids = reinterpret_cast<int *>(base + e);
-  int *deg_sorted = reinterpret_cast<int *>(base + 2 * e);
-  int *nseg = reinterpret_cast<int *>(base + 3 * e);
-  int *multi = reinterpret_cast<int *>(base + 4 * e);
-  int *item_off = reinterpret_cast<int *>(base + 5 * e);
-  int *multi_off = reinterpret_cast<int *>(base + 6 * e);
-  void *cub = base + 7 * e;
+  PlanKey *keys = reinterpret_cast<PlanKey *>(base);
+  PlanKey *sorted = reinterpret_cast<PlanKey *>(base + k);
+  base += 2 * k;
+  int *ids = reinterpret_cast<int *>(base);
+  int *nseg = reinterpret_cast<int *>(base + e);
+  int *multi = reinterpret_cast<int *>(base + 2 * e);
+  int *item_off = reinterpret_cast<int *>(base + 3 * e);
+  int *multi_off = reinterpret_cast<int *>(base + 4 * e);
+  void *cub = base + 5 * e;
   const size_t cub_bytes = (size_t)scratch_bytes - (size_t)(static_cast<char *>(cub) - static_cast<char *>(scratch));
 
   INCAGG_HIP_TRY(hipMemsetAsync(st, 0, sizeof(PlanStatus), stream));
   const dim3 grid(grid_for(n)), block(kBlock);
-  hipLaunchKernelGGL(plan_degrees_kernel, grid, block, 0, stream, rowptr, n, deg, ids, st);
+  hipLaunchKernelGGL(plan_keys_kernel, grid, block, 0, stream, rowptr, n, hub_threshold,
+                     plan_chunk_rows(n), keys, ids, st);
   INCAGG_HIP_TRY(hipGetLastError());
-  // radix sort, descending and stable: ties keep ascending row ids, like the host builder
+  // radix sort, stable: ties keep ascending row ids, like the host builder
   size_t tmp = cub_bytes;
-  INCAGG_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(cub, tmp, deg, deg_sorted, ids, order, n, 0,
-                                                              32, stream));
-  hipLaunchKernelGGL(plan_segments_kernel, grid, block, 0, stream, deg_sorted, n, hub_threshold,
-                     segment_edges, nseg, multi);
+  INCAGG_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, tmp, keys, sorted, ids, order, n, 0,
+                                                    kPlanKeyBits, stream));
+  hipLaunchKernelGGL(plan_segments_kernel, grid, block, 0, stream, sorted, n, segment_edges, nseg,
+                     multi);
   INCAGG_HIP_TRY(hipGetLastError());
   tmp = cub_bytes;
   INCAGG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, tmp, nseg, item_off, n, stream));
   tmp = cub_bytes;
   INCAGG_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, tmp, multi, multi_off, n, stream));
-  hipLaunchKernelGGL(plan_fill_kernel, grid, block, 0, stream, order, deg_sorted, nseg, item_off,
-                     multi_off, n, hub_threshold, (long long)items_cap, (long long)multi_cap,
+  hipLaunchKernelGGL(plan_fill_kernel, grid, block, 0, stream, order, sorted, nseg, item_off,
+                     multi_off, n, (long long)items_cap, (long long)multi_cap,
                      reinterpret_cast<int2 *>(items), multi_rows, st);
   INCAGG_HIP_TRY(hipGetLastError());
   *status_out = st;
@@ -265,7 +290,7 @@ extern "C" int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, in
 namespace incagg {
 
 constexpr int64_t kStaticPlanRows = 262144;
-constexpr size_t kStaticPlanBytes = 12u << 20;
+constexpr size_t kStaticPlanBytes = 16u << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticPlanBytes];
 
 static constexpr int kMaxPlanDevices = 64;

@@ -25,6 +25,7 @@ SIGNATURES = {
                                           _i64, _int, _f32, _vp, _i64, _f32, _i64, _vp, _vp,
                                           _i64, _vp]),
     "incagg_spmm_plan_defaults": (_int, [_vp, _vp]),
+    "incagg_spmm_plan_chunk_rows": (_i32, [_i64]),
     "incagg_spmm_plan_items_bound": (_i64, [_i64, _i64, _i32, _i32]),
     "incagg_spmm_plan_host": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
     "incagg_spmm_plan_device_scratch_bytes": (_i64, [_i64]),

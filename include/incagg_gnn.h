@@ -94,7 +94,7 @@ int incagg_check_device_errors(void);
  * call allocates nothing, keeps no state between calls and may be recorded into a HIP graph.
  */
 typedef struct incagg_spmm_plan {
-  const int32_t *order;      /* device int32[n_rows]: rows by descending length, ties by row id */
+  const int32_t *order;      /* device int32[n_rows]: a permutation of the rows, the long ones first */
   const int32_t *items;      /* device int32[2 * n_items]: (row, segment) of the long rows */
   const int32_t *multi_rows; /* device int32[n_multi]: rows with more than one segment */
   int64_t n_rows;
@@ -161,7 +161,15 @@ int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col, const 
  * Work plan of an aggregation: a pure function of the row pointers, built once per batch next
  * to the relabelling (it replaces the per-step mask / sort work of models/gcn.py:117-135 and
  * has no other counterpart in the reference, whose SpMM kernels live in torch-sparse).
- *   order[n_rows]        rows by descending length (stable: ties in ascending row id)
+ *   order[n_rows]        the n_hub rows longer than hub_threshold first, then the others; each
+ *                        part by descending length (stable: ties in ascending row id).  When
+ *                        incagg_spmm_plan_chunk_rows(n_rows) > 0 (matrices of more than 32,768
+ *                        rows: 1,024) each part is ordered chunk by chunk instead -- the rows of
+ *                        ids [0, chunk) first, then [chunk, 2 chunk), ..., every chunk by
+ *                        descending length: rows of one partition of a batch are neighbours and
+ *                        gather mostly from each other, so processing them together keeps their
+ *                        sources in the L2.  The kernels accept any permutation whose first n_hub
+ *                        entries are the rows that `items` covers.
  *   items[2 * n_items]   for the n_hub rows longer than hub_threshold, in that order, one
  *                        (row, segment) pair per started segment of segment_edges edges
  *   multi_rows[n_multi]  the rows with more than one segment
@@ -175,6 +183,7 @@ int incagg_spmm_csr_incagg_f32(const int32_t *rowptr, const int32_t *col, const 
  *   counts come back).  Both produce identical arrays.
  */
 int incagg_spmm_plan_defaults(int32_t *hub_threshold, int32_t *segment_edges);
+int32_t incagg_spmm_plan_chunk_rows(int64_t n_rows);
 int64_t incagg_spmm_plan_items_bound(int64_t n_rows, int64_t nnz, int32_t hub_threshold,
                                      int32_t segment_edges);
 int incagg_spmm_plan_host(const int32_t *rowptr, int64_t n_rows, int32_t hub_threshold,
@@ -192,7 +201,7 @@ int incagg_spmm_plan_device(const int32_t *rowptr, int64_t n_rows, int32_t hub_t
  * incagg_spmm_plan_device without any allocation, workspace argument, host copy or wait.  It
  * has no counterpart in the reference; it is for callers that cannot allocate: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  The work arrays live
- * in a fixed 12 MiB array of the library's code object (one copy per GPU, held until the
+ * in a fixed 16 MiB array of the library's code object (one copy per GPU, held until the
  * process ends), which bounds the input: 1 <= n_rows <= incagg_spmm_plan_device_static_max_rows()
  * (262,144); larger inputs are rejected with INCAGG_E_INVALID.  Outputs are those of
  * incagg_spmm_plan_device, element for element; the counts stay on the device:
@@ -212,7 +221,9 @@ int incagg_spmm_plan_device_static(const int32_t *rowptr, int64_t n_rows, int32_
  * tests).  Keys: "spmm_variant" (-1 feature slices whenever the rows are 16-byte aligned, 0
  * always whole rows per wave, 1 as -1), "hub_threshold", "segment_edges" (defaults of the plan
  * builders), "wide_addressing" (1: split-source launches always use 64-bit row offsets, -1: the
- * 24-bit multiply-add form whenever row ids and pitches allow).  Not thread-safe against concurrent aggregation calls.
+ * 24-bit multiply-add form whenever row ids and pitches allow), "plan_local_rows" (matrices of
+ * more rows get the chunk-by-chunk row order; 32768), "plan_chunk_rows" (rows per chunk; 1024, 0:
+ * never chunked).  Not thread-safe against concurrent aggregation calls.
  */
 int incagg_set_tuning(const char *key, int value);
 

@@ -16,8 +16,9 @@ def _np(t):
 
 
 def _check_plan(plan, rowptr32):
-    """The plan must describe the rows the call addresses: a permutation by descending length
-    whose long prefix is covered segment by segment."""
+    """The plan must describe the rows the call addresses: a permutation, long rows first, each
+    part by (chunk of the row, descending length, row id), whose long prefix is covered segment
+    by segment."""
     if plan is None:
         return
     n_rows = rowptr32.numel() - 1
@@ -25,8 +26,12 @@ def _check_plan(plan, rowptr32):
     order = plan.order.to(torch.int64).cpu()
     assert torch.equal(torch.sort(order).values, torch.arange(n_rows))
     deg = (rowptr32[1:] - rowptr32[:-1]).to(torch.int64).cpu()
-    d = deg[order]
-    assert torch.all(d[:-1] >= d[1:]) if n_rows > 1 else True
+    from torch_geometric_autoscale import _lib
+    chunk = int(_lib.lib().incagg_spmm_plan_chunk_rows(n_rows))
+    rows = torch.arange(n_rows)
+    key = ((deg <= plan.hub_threshold).to(torch.int64) << 62) \
+        | ((rows // chunk if chunk else torch.zeros_like(rows)) << 31) | (0x7fffffff - deg)
+    assert torch.equal(order, torch.sort(key, stable=True).indices)
     assert plan.n_hub == int((deg > plan.hub_threshold).sum())
     want = [(int(r), s) for r in order[:plan.n_hub].tolist()
             for s in range(-(-int(deg[r]) // plan.segment_edges))]

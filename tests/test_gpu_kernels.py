@@ -313,9 +313,83 @@ def test_plan_host_and_device_builders_agree(ops, dev):
             assert torch.equal(h.order, d.order.cpu())
             assert torch.equal(h.items[:h.n_items], d.items[:d.n_items].cpu())
             assert torch.equal(h.multi_rows[:h.n_multi], d.multi_rows[:d.n_multi].cpu())
-            deg = np.diff(rowptr[lo:hi + 2 - 1 + 0]) if False else np.diff(rowptr[lo:hi + 1])
+            deg = np.diff(rowptr[lo:hi + 1])
             assert h.n_hub == int((deg > h.hub_threshold).sum())
             assert h.n_items == int(sum(-(-x // h.segment_edges) for x in deg[deg > h.hub_threshold]))
+            _check_plan_order(h, deg)
+
+
+def _check_plan_order(plan, deg):
+    """Long rows first; each part by (chunk of the row, descending length, row id)."""
+    from torch_geometric_autoscale import _lib
+    n = deg.size
+    chunk = int(_lib.lib().incagg_spmm_plan_chunk_rows(n))
+    rows = np.arange(n)
+    key = np.stack([deg <= plan.hub_threshold, rows // chunk if chunk else 0 * rows, -deg, rows])
+    want = np.lexsort(key[::-1])
+    assert np.array_equal(plan.order.numpy(), want)
+
+
+@pytest.fixture
+def chunked_plans():
+    """Plans of matrices of more than 300 rows ordered in chunks of 64 rows."""
+    from torch_geometric_autoscale import _lib
+    _lib.set_tuning("plan_local_rows", 300)
+    _lib.set_tuning("plan_chunk_rows", 64)
+    yield
+    _lib.set_tuning("plan_local_rows", 32768)
+    _lib.set_tuning("plan_chunk_rows", 1024)
+
+
+def test_chunked_plan_order(ops, dev, chunked_plans):
+    """Large matrices: rows ordered chunk by chunk, by both builders alike; the default
+    thresholds on a matrix of 40 000 rows, small ones forced on a matrix of 3 000."""
+    from torch_geometric_autoscale import _lib
+    rng = np.random.default_rng(6)
+    rowptr, _, _ = random_csr(rng, 3000, 9000, 14, hubs={0: 129, 5: 128, 17: 4097, 70: 1025,
+                                                         2999: 8000}, empty_rows=(1, 2, 2998),
+                              weighted=False)
+    cases = [(rowptr, 64)]
+    _lib.set_tuning("plan_local_rows", 32768)
+    _lib.set_tuning("plan_chunk_rows", 1024)
+    big, _, _ = random_csr(rng, 40000, 9000, 5, hubs={7: 300, 39000: 5000}, weighted=False)
+    assert int(_lib.lib().incagg_spmm_plan_chunk_rows(40000)) == 1024
+    assert int(_lib.lib().incagg_spmm_plan_chunk_rows(32768)) == 0
+    for rp_np, chunk in ((big, 1024), (rowptr, 64)):
+        if chunk == 64:
+            _lib.set_tuning("plan_local_rows", 300)
+            _lib.set_tuning("plan_chunk_rows", 64)
+        rp = torch.from_numpy(rp_np.astype(np.int32))
+        h, d = ops.SpmmPlan.build(rp), ops.SpmmPlan.build(rp.to(dev))
+        assert (h.n_hub, h.n_items, h.n_multi) == (d.n_hub, d.n_items, d.n_multi)
+        assert torch.equal(h.order, d.order.cpu())
+        assert torch.equal(h.items[:h.n_items], d.items[:d.n_items].cpu())
+        assert torch.equal(h.multi_rows[:h.n_multi], d.multi_rows[:d.n_multi].cpu())
+        deg = np.diff(rp_np)
+        assert int(_lib.lib().incagg_spmm_plan_chunk_rows(deg.size)) == chunk
+        _check_plan_order(h, deg)
+        first_short = h.order[h.n_hub:h.n_hub + 8].numpy()
+        assert np.all(first_short < chunk)          # chunk 0 leads the short rows
+
+
+@pytest.mark.parametrize("width", [8, 41, 64, 128, 256])
+def test_spmm_with_chunked_plan_matches_oracle(ops, dev, width, chunked_plans):
+    """Narrow matrices under a chunk-ordered plan: the workgroups of an XCD walk one contiguous
+    range of the plan (1, 2 and 4 slices; 8 slices as before)."""
+    from torch_geometric_autoscale import _lib
+    rng = np.random.default_rng(width)
+    for b, m in ((1900, 5000), (333, 333)):
+        rowptr, col, val = random_csr(rng, b, m, 9, hubs={3: 700, 64: 4200, b - 1: 130},
+                                      empty_rows=(9, 65), weighted=True)
+        x = rng.standard_normal((m, width)).astype(np.float32)
+        h64 = cp.spmm_f64(rowptr, col, val, x, "sum")
+        rp, c, v = _dev_csr(rowptr, col, val, dev)
+        plan = ops.SpmmPlan.build(rp)
+        xd = ops.rows_empty(m, width, dev)
+        xd.copy_(torch.from_numpy(x))
+        _check(ops.spmm_csr(rp, c, v, xd, m, plan=plan), h64)
+        _check(ops.spmm_csr(rp, c, v, xd, m, plan=plan.with_edges(ops.pack_edges(c, v))), h64)
+    _lib.check_device_errors()
 
 
 @pytest.mark.parametrize("width", [256, 128, 41, 512])

@@ -46,7 +46,9 @@ def test_static_plan_builder_matches_the_workspace_builder():
                                                         199999: 30000}, empty_rows=(1, 2, 77777),
                            weighted=False)
     small, _, _ = random_csr(rng, 3001, 9000, 14, hubs={3: 5000, 2999: 300}, weighted=False)
-    for rowptr, kw in ((big, (0, 0)), (small, (24, 128)), (big[:1000], (0, 0))):
+    # (the largest input the fixed array takes: 262 144 rows; then smaller ones)
+    most = np.arange(262145, dtype=np.int64) * 3
+    for rowptr, kw in ((most, (0, 0)), (big, (0, 0)), (small, (24, 128)), (big[:1000], (0, 0))):
         rp = torch.from_numpy(rowptr.astype(np.int32)).to(dev)
         nnz = int(rowptr[-1] - rowptr[0])
         want = ops.SpmmPlan.build(rp, nnz, hub_threshold=kw[0], segment_edges=kw[1])
