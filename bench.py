@@ -413,9 +413,13 @@ def main():
     def padded(g, n_):      # a gradient, zero-extended to its parameter's slot
         g = g.reshape(-1)
         return g if g.numel() == n_ else torch.nn.functional.pad(g, (0, n_ - g.numel()))
-    opt_flat = torch.optim.Adam([flat_w], lr=1e-3, fused=True)
-    opt = torch.optim.Adam(train_params, lr=1e-3, fused=True, capturable=use_graphs)
-    crit = torch.nn.CrossEntropyLoss()
+    # torch.optim.Adam's update and torch.nn.CrossEntropyLoss's value (main.py:60,160-165), each
+    # in fewer, fuller launches (optim.Adam: step counts on the device, so recorded steps count on)
+    from torch_geometric_autoscale.optim import Adam
+    from torch_geometric_autoscale.nn import CrossEntropyLoss
+    opt_flat = Adam([flat_w], lr=1e-3)
+    opt = Adam(train_params, lr=1e-3)
+    crit = CrossEntropyLoss()
     model.train()
     setup_s = time.perf_counter() - t_setup
 

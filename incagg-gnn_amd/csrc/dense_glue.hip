@@ -7,7 +7,9 @@
 // full hipBLASLt launch, ~14 us, for a few thousand multiply-adds).  fp32, fixed summation order.
 #include "common.h"
 
+#include <algorithm>
 #include <climits>
+#include <cmath>
 
 namespace incagg {
 
@@ -46,5 +48,334 @@ extern "C" int incagg_tn_finish_f32(const float *parts, int64_t n_parts, const f
                      static_cast<hipStream_t>(stream), parts, (int)n_parts, m * n, a_tail, lda,
                      b_tail, ldb, (int)n_tail, (int)m, (int)n, out, ldo);
   INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+// =====================================================================================
+// The rest of the dense side's glue: reductions and element-wise passes that torch runs in
+// several launches with little parallelism each.  None of them has a counterpart in the
+// reference's own sources (it calls torch.nn.functional / torch.optim, main.py:60-90).
+// =====================================================================================
+namespace incagg {
+
+// ---- column sums of a tall matrix (bias gradients): out[c] = sum_r x[r, c] ----------------
+// Two passes over a caller-provided workspace: every workgroup sums `rows_per_block` rows (a
+// wave reads 64 x 16 bytes of one row per instruction, the four waves take rows r, r+4, ...)
+// into one partial row; the second pass sums the partial rows.  Fixed summation order.
+constexpr int kColsumCols = 256;  // columns per workgroup: 64 lanes x 4
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float *x, long long ldx, int rows,
+                                                     int width, int rows_per_block, float *out,
+                                                     long long ldo, int vec) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * kColsumCols + lane * 4;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec) {  // rows 16-byte aligned, width a multiple of 4
+    if (c < width) {
+      int r = r0 + wave;
+      for (; r + 12 < r1; r += 16) {  // four loads in flight
+        const float4 a = *reinterpret_cast<const float4 *>(x + (long long)r * ldx + c);
+        const float4 b = *reinterpret_cast<const float4 *>(x + (long long)(r + 4) * ldx + c);
+        const float4 d = *reinterpret_cast<const float4 *>(x + (long long)(r + 8) * ldx + c);
+        const float4 e = *reinterpret_cast<const float4 *>(x + (long long)(r + 12) * ldx + c);
+        acc.x += (a.x + b.x) + (d.x + e.x);
+        acc.y += (a.y + b.y) + (d.y + e.y);
+        acc.z += (a.z + b.z) + (d.z + e.z);
+        acc.w += (a.w + b.w) + (d.w + e.w);
+      }
+      for (; r < r1; r += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + (long long)r * ldx + c);
+        acc.x += a.x;
+        acc.y += a.y;
+        acc.z += a.z;
+        acc.w += a.w;
+      }
+    }
+  } else {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const float *p = x + (long long)r * ldx + c;
+      if (c < width) acc.x += p[0];
+      if (c + 1 < width) acc.y += p[1];
+      if (c + 2 < width) acc.z += p[2];
+      if (c + 3 < width) acc.w += p[3];
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  const float4 a = part[0][lane], b = part[1][lane], d = part[2][lane], e = part[3][lane];
+  float *o = out + (long long)blockIdx.x * ldo + c;
+  if (c < width) o[0] = (a.x + b.x) + (d.x + e.x);
+  if (c + 1 < width) o[1] = (a.y + b.y) + (d.y + e.y);
+  if (c + 2 < width) o[2] = (a.z + b.z) + (d.z + e.z);
+  if (c + 3 < width) o[3] = (a.w + b.w) + (d.w + e.w);
+}
+
+static inline int colsum_rows_per_block(long long rows) {
+  return (int)std::max<long long>(64, (rows + 1023) / 1024);  // at most 1024 partial rows
+}
+
+// ---- mean softmax cross entropy over rows, and its gradient --------------------------------
+// One wave per row.  Forward: lse[r] = log sum_c exp(logits[r, c]) and one partial loss sum per
+// workgroup (summed by a single workgroup afterwards: fixed order).  Backward:
+// dlogits[r, c] = dloss * (exp(logits[r, c] - lse[r]) - [c == label[r]]) / rows.
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void xent_forward_kernel(const float *logits, long long ld,
+                                                           const long long *labels, int rows,
+                                                           int classes, float *lse, float *part,
+                                                           int *err) {
+  __shared__ float row_loss[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  float loss = 0.f;
+  if (r < rows) {
+    const float *p = logits + (long long)r * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < classes; c += 64) mx = fmaxf(mx, p[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < classes; c += 64) s += __expf(p[c] - mx);
+    const float l = mx + __logf(wave_sum(s));
+    const long long y = labels[r];
+    if (y < 0 || y >= classes) {
+      if (lane == 0) *err = 1;  // reported; the row counts as loss 0
+    } else {
+      loss = l - p[y];
+    }
+    if (lane == 0) lse[r] = l;
+  }
+  if (lane == 0) row_loss[wave] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (row_loss[0] + row_loss[1]) + (row_loss[2] + row_loss[3]);
+}
+
+__global__ __launch_bounds__(256) void xent_finish_kernel(const float *part, int n, float inv_rows,
+                                                          float *loss) {
+  __shared__ float acc[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  acc[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) acc[threadIdx.x] += acc[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = acc[0] * inv_rows;
+}
+
+__global__ __launch_bounds__(256) void xent_backward_kernel(const float *logits, long long ld,
+                                                            const long long *labels,
+                                                            const float *lse, int rows, int classes,
+                                                            const float *dloss, float *dlogits,
+                                                            long long ldd) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float g = *dloss / (float)rows, l = lse[r];
+  const long long y = labels[r];
+  const bool ok = y >= 0 && y < classes;
+  const float *p = logits + (long long)r * ld;
+  float *d = dlogits + (long long)r * ldd;
+  for (int c = lane; c < classes; c += 64)
+    d[c] = ok ? g * (__expf(p[c] - l) - (c == y ? 1.f : 0.f)) : 0.f;
+}
+
+// ---- Adam step over a list of parameter tensors, one launch -------------------------------
+// torch.optim.Adam's update (no amsgrad, no maximize): g' = g + wd p; m += (g' - m)(1 - b1);
+// v = b2 v + (1 - b2) g'^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), with
+// t = *step + 1, every tensor's own count, read from device memory (the launch can sit in a HIP
+// graph); the workgroup that finishes last stores the counts back.  Workgroup b handles 1024
+// consecutive elements of ONE tensor.
+constexpr int kAdamSegments = 24;
+struct AdamTable {
+  float *p[kAdamSegments];
+  const float *g[kAdamSegments];
+  float *m[kAdamSegments];
+  float *v[kAdamSegments];
+  float *step[kAdamSegments];
+  int n[kAdamSegments];
+  int first_block[kAdamSegments + 1];
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, int n_seg, float lr, float b1,
+                                                   float b2, float eps, float wd, int *arrivals) {
+  __shared__ float s_step;
+  int seg = 0;
+  while (seg + 1 < n_seg && (int)blockIdx.x >= t.first_block[seg + 1]) seg++;  // scalar
+  if (threadIdx.x == 0) s_step = *t.step[seg];
+  __syncthreads();
+  const float s = s_step, tt = s + 1.f;
+  const int n = t.n[seg];
+  const int i0 = ((int)blockIdx.x - t.first_block[seg]) * 1024 + (int)threadIdx.x * 4;
+  const float bc1 = 1.f - powf(b1, tt), bc2_sqrt = sqrtf(1.f - powf(b2, tt));
+  const float step_size = lr / bc1;
+  float *p = t.p[seg], *m = t.m[seg], *v = t.v[seg];
+  const float *g = t.g[seg];
+  auto one = [&](float &pp, float gg, float &mm, float &vv) {
+    gg += wd * pp;
+    mm += (gg - mm) * (1.f - b1);
+    vv = vv * b2 + (1.f - b2) * gg * gg;
+    pp -= step_size * mm / (sqrtf(vv) / bc2_sqrt + eps);
+  };
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                     reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+  if (i0 + 4 <= n && vec) {
+    float4 pp = *reinterpret_cast<float4 *>(p + i0), mm = *reinterpret_cast<float4 *>(m + i0);
+    float4 vv = *reinterpret_cast<float4 *>(v + i0);
+    const float4 gg = *reinterpret_cast<const float4 *>(g + i0);
+    one(pp.x, gg.x, mm.x, vv.x);
+    one(pp.y, gg.y, mm.y, vv.y);
+    one(pp.z, gg.z, mm.z, vv.z);
+    one(pp.w, gg.w, mm.w, vv.w);
+    *reinterpret_cast<float4 *>(p + i0) = pp;
+    *reinterpret_cast<float4 *>(m + i0) = mm;
+    *reinterpret_cast<float4 *>(v + i0) = vv;
+  } else {
+    for (int i = i0; i < min(i0 + 4, n); i++) one(p[i], g[i], m[i], v[i]);
+  }
+  // Every thread of this workgroup has its copy of the old step count (through LDS, above).
+  // The arrival's operand depends on that value, so the count cannot be issued ahead of the
+  // read: when the last workgroup arrives, nobody needs the old counts any more.
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int one_more = 1 + (__float_as_int(s) & 0);
+    s_last = atomicAdd(arrivals, one_more) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if ((int)threadIdx.x < n_seg) {
+    // (tensors may share a counter: written once, by the first segment that names it)
+    bool first = true;
+    for (int k = 0; k < (int)threadIdx.x; k++) first = first && t.step[k] != t.step[threadIdx.x];
+    if (first) *t.step[threadIdx.x] += 1.f;
+  }
+  if (threadIdx.x == 0) atomicExch(arrivals, 0);
+}
+
+}  // namespace incagg
+
+extern "C" int64_t incagg_column_sums_ws_floats(int64_t rows, int64_t width) {
+  if (rows < 0 || width < 0) return fail(INCAGG_E_INVALID, "negative size");
+  const int rpb = colsum_rows_per_block(rows);
+  return ((rows + rpb - 1) / rpb) * width;
+}
+
+extern "C" int incagg_column_sums_f32(const float *x, int64_t ldx, int64_t rows, int64_t width,
+                                      float *ws, int64_t ws_floats, float *out, void *stream_) {
+  INCAGG_REQUIRE(rows >= 0 && width >= 0 && rows < INT_MAX && width < INT_MAX, "size out of range");
+  if (width == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(out != nullptr, "null output");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (rows == 0) {
+    INCAGG_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)width, stream));
+    return INCAGG_OK;
+  }
+  INCAGG_REQUIRE(x && ldx >= width, "null input or ldx < width");
+  const int rpb = colsum_rows_per_block(rows);
+  const int n_part = (int)((rows + rpb - 1) / rpb);
+  INCAGG_REQUIRE(ws && ws_floats >= (int64_t)n_part * width, "workspace too small: %lld < %lld",
+                 (long long)ws_floats, (long long)n_part * width);
+  const unsigned col_blocks = (unsigned)((width + kColsumCols - 1) / kColsumCols);
+  const int vec = aligned16(x) && ldx % 4 == 0 && width % 4 == 0;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)n_part, col_blocks), dim3(256), 0, stream, x, ldx,
+                     (int)rows, (int)width, rpb, ws, width, vec);
+  INCAGG_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(colsum_kernel, dim3(1, col_blocks), dim3(256), 0, stream, ws, width, n_part,
+                     (int)width, n_part, out, width, (int)(aligned16(ws) && width % 4 == 0));
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+extern "C" int64_t incagg_softmax_xent_ws_floats(int64_t rows) {
+  if (rows < 0) return fail(INCAGG_E_INVALID, "negative size");
+  return rows + (rows + 3) / 4;  // lse per row + one partial loss per workgroup
+}
+
+extern "C" int incagg_softmax_xent_forward_f32(const float *logits, int64_t ld,
+                                               const int64_t *labels, int64_t rows,
+                                               int64_t classes, float *ws, int64_t ws_floats,
+                                               float *loss, void *stream_) {
+  INCAGG_REQUIRE(rows >= 1 && classes >= 1 && rows < INT_MAX - 4 && classes < INT_MAX,
+                 "size out of range");
+  INCAGG_REQUIRE(logits && labels && loss && ld >= classes, "null argument or ld < classes");
+  INCAGG_REQUIRE(ws && ws_floats >= incagg_softmax_xent_ws_floats(rows), "workspace too small");
+  int *err = nullptr;
+  int rc = error_flag_address(&err);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int blocks = (int)((rows + 3) / 4);
+  hipLaunchKernelGGL(xent_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, logits, ld,
+                     reinterpret_cast<const long long *>(labels), (int)rows, (int)classes, ws,
+                     ws + rows, err);
+  INCAGG_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(256), 0, stream, ws + rows, blocks,
+                     1.0f / (float)rows, loss);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_softmax_xent_backward_f32(const float *logits, int64_t ld,
+                                                const int64_t *labels, int64_t rows,
+                                                int64_t classes, const float *ws,
+                                                const float *dloss, float *dlogits, int64_t ldd,
+                                                void *stream_) {
+  INCAGG_REQUIRE(rows >= 1 && classes >= 1 && rows < INT_MAX - 4 && classes < INT_MAX,
+                 "size out of range");
+  INCAGG_REQUIRE(logits && labels && ws && dloss && dlogits && ld >= classes && ldd >= classes,
+                 "null argument or a pitch below the class count");
+  hipLaunchKernelGGL(xent_backward_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), logits, ld,
+                     reinterpret_cast<const long long *>(labels), ws, (int)rows, (int)classes, dloss,
+                     dlogits, ldd);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay,
+                                    int32_t *arrivals, void *stream_) {
+  INCAGG_REQUIRE(n_segs >= 0 && (n_segs == 0 || segs), "bad segment list");
+  INCAGG_REQUIRE(arrivals, "null arrival counter");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  // launches of up to kAdamSegments tensors each
+  int64_t first = 0;
+  while (first < n_segs) {
+    AdamTable t{};
+    int k = 0, blocks = 0;
+    int64_t i = first;
+    for (; i < n_segs && k < kAdamSegments; i++) {
+      const incagg_adam_segment &s = segs[i];
+      INCAGG_REQUIRE(s.n >= 0 && s.n < INT_MAX - 1024, "segment length out of range");
+      if (s.n == 0) continue;
+      INCAGG_REQUIRE(s.p && s.g && s.m && s.v && s.step, "null segment pointer");
+      t.step[k] = s.step;
+      t.p[k] = s.p;
+      t.g[k] = s.g;
+      t.m[k] = s.m;
+      t.v[k] = s.v;
+      t.n[k] = (int)s.n;
+      t.first_block[k] = blocks;
+      blocks += (int)((s.n + 1023) / 1024);
+      INCAGG_REQUIRE(blocks < (1 << 30), "grid too large");
+      k++;
+    }
+    t.first_block[k] = blocks;
+    first = i;
+    if (k == 0) break;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, k, lr, beta1,
+                       beta2, eps, weight_decay, arrivals);
+    INCAGG_HIP_TRY(hipGetLastError());
+  }
   return INCAGG_OK;
 }

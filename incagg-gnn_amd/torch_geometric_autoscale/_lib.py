@@ -37,6 +37,12 @@ SIGNATURES = {
     "incagg_set_tuning": (_int, [_c.c_char_p, _int]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_tn_finish_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "incagg_column_sums_ws_floats": (_i64, [_i64, _i64]),
+    "incagg_column_sums_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "incagg_softmax_xent_ws_floats": (_i64, [_i64]),
+    "incagg_softmax_xent_forward_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "incagg_softmax_xent_backward_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "incagg_adam_step_f32": (_int, [_vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "incagg_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "incagg_scatter_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "incagg_copy_row_chunks_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp,
@@ -70,6 +76,11 @@ class SpmmFuseStruct(_c.Structure):
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1}
 ABI_VERSION = 3
+
+
+class AdamSegment(_c.Structure):
+    """``incagg_adam_segment`` of include/incagg_gnn.h."""
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("step", _vp), ("n", _i64)]
 
 
 class SpmmPlanStruct(_c.Structure):

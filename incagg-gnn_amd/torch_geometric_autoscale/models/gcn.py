@@ -29,7 +29,7 @@ class GCN(ScalableGNN):
         self.lins = ModuleList()
         if linear:
             self.lins.append(RowsLinear(in_channels, hidden_channels))
-            self.lins.append(RowsLinear(hidden_channels, out_channels))
+            self.lins.append(RowsLinear(hidden_channels, out_channels, gathered=False))
 
         self.convs = ModuleList()
         for i in range(num_layers):

@@ -29,7 +29,7 @@ class GCN2(ScalableGNN):
 
         self.lins = ModuleList()
         self.lins.append(RowsLinear(in_channels, hidden_channels))
-        self.lins.append(RowsLinear(hidden_channels, out_channels))
+        self.lins.append(RowsLinear(hidden_channels, out_channels, gathered=False))
 
         self.convs = ModuleList([
             GCN2Conv(hidden_channels, alpha=alpha, theta=theta, layer=i + 1,

@@ -65,12 +65,15 @@ def _tn_product(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 def _column_sums(x: Tensor) -> Tensor:
-    """``x.sum(0)`` of a tall matrix (bias gradients) in two stages: 64 row slabs reduced side
-    by side, then the 64 partial rows.  torch's single reduction runs such shapes in 64
-    workgroups (16k x 47: 39 us -> 13 us; 128k x 256: 44 us -> 38 us on MI355X)."""
+    """``x.sum(0)`` of a tall matrix (bias gradients).  On the GPU: ops.column_sums (two
+    launches at streaming rate; 128k x 256: 54 us in four torch launches -> 27 us, 16k x 47:
+    20 -> 7 us on MI355X).  Elsewhere in two stages: 64 row slabs reduced side by side, then
+    the 64 partial rows."""
     rows = x.size(0)
     if rows < 4096 or x.dim() != 2:
         return x.sum(0)
+    if x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1:
+        return ops.column_sums(x)
     k = (rows // 64) * 64
     if k == rows:
         return x.unflatten(0, (64, k // 64)).sum(1).sum(0)
@@ -80,13 +83,28 @@ def _column_sums(x: Tensor) -> Tensor:
     return part.sum(0)
 
 
+class CrossEntropyLoss:
+    """``torch.nn.CrossEntropyLoss()`` with its defaults (main.py:60): the fused HIP form
+    (ops.softmax_cross_entropy) for fp32 logits on the GPU, torch's own elsewhere."""
+
+    def __call__(self, logits: Tensor, target: Tensor) -> Tensor:
+        if (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+                and target.dtype == torch.int64 and target.dim() == 1 and logits.size(0) > 0):
+            if logits.stride(1) != 1:
+                logits = logits.contiguous()
+            return ops.softmax_cross_entropy(logits, target.contiguous())
+        return torch.nn.functional.cross_entropy(logits, target)
+
+
 class _RowsLinear(torch.autograd.Function):
     """``x @ W^T + b`` over node rows with the weight gradient evaluated by :func:`_tn_product`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, gathered=True):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if not gathered:    # plain contiguous result (bias in the GEMM's epilogue)
+            return x @ weight.t() if bias is None else torch.addmm(bias, x, weight.t())
         if bias is None:
             return _mm_rows(x, weight.t())
         if not x.is_cuda or x.dim() != 2:
@@ -101,7 +119,7 @@ class _RowsLinear(torch.autograd.Function):
         dx = _mm_rows(dy, weight) if ctx.needs_input_grad[0] else None
         dw = _tn_product(dy, x) if ctx.needs_input_grad[1] else None
         db = _column_sums(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class _EmbedRelu(torch.autograd.Function):
@@ -208,6 +226,32 @@ class _Layers(torch.autograd.Function):
         return gs, None
 
 
+class _FoldedSideBySide(torch.autograd.Function):
+    """``[C, L*C]`` matrix whose column block l is ``const_l + scale_l * stack[l]`` (the folded
+    second weights of all layers laid out for ONE wide GEMM), from the ``[L, C, C]`` stack of
+    the weights.  One launch forward; backward one launch that writes the gradient of the
+    stack contiguously, so that the per-layer gradients are slices nobody has to copy
+    (cutting column blocks out of a ``[C, L*C]`` gradient costs a copy per layer)."""
+
+    @staticmethod
+    def forward(ctx, stack, const_cat, scale_cat):
+        n_layers, c, _ = stack.shape
+        ctx.save_for_backward(scale_cat)
+        out = torch.addcmul(const_cat.view(c, n_layers, c), stack.permute(1, 0, 2),
+                            scale_cat.view(1, n_layers, c))
+        return out.view(c, n_layers * c)
+
+    @staticmethod
+    def backward(ctx, d):
+        scale_cat, = ctx.saved_tensors
+        c = d.size(0)
+        n_layers = d.size(1) // c
+        out = torch.empty((n_layers, c, c), dtype=d.dtype, device=d.device)
+        torch.mul(d.view(c, n_layers, c).permute(1, 0, 2),
+                  scale_cat.view(n_layers, 1, c), out=out)
+        return out, None, None
+
+
 class _X0Terms(torch.autograd.Function):
     """``x_0 @ [W_1 | ... | W_L]`` handed out as the L column blocks ``[rows, C]`` of ONE
     ``[rows, L*C]`` matrix.  ``grad_stack``: a matrix of that shape whose column blocks the
@@ -249,12 +293,19 @@ class _X0Terms(torch.autograd.Function):
 
 
 class RowsLinear(Linear):
-    """``torch.nn.Linear`` (same parameters, same state dict) for [rows, features] inputs."""
+    """``torch.nn.Linear`` (same parameters, same state dict) for [rows, features] inputs.
+    ``gathered=False``: nothing aggregates over the output (a model's last layer), so it gets
+    no padded row pitch -- with a width such as 47 the padded form costs two extra copies."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True,
+                 gathered: bool = True):
+        super().__init__(in_features, out_features, bias=bias)
+        self.gathered = gathered
 
     def forward(self, x: Tensor) -> Tensor:
         if x.dim() != 2 or not x.is_cuda:
             return super().forward(x)
-        return _RowsLinear.apply(x, self.weight, self.bias)
+        return _RowsLinear.apply(x, self.weight, self.bias, self.gathered)
 
 
 def glorot_(w: Tensor) -> None:
@@ -414,7 +465,7 @@ def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
             (alpha * beta).repeat_interleave(c).view(1, -1).contiguous())
     c1, b1, c2cat, b2cat = consts[key]
     w1f = torch.addcmul(c1, torch.stack([conv.weight1 for conv in convs]), b1)
-    w2cat = torch.addcmul(c2cat, torch.cat([conv.weight2 for conv in convs], dim=1), b2cat)
+    w2cat = _FoldedSideBySide.apply(torch.stack([conv.weight2 for conv in convs]), c2cat, b2cat)
     terms = _X0Terms.apply(x_0, w2cat, n_layers, grad_stack)
     if not (torch.is_grad_enabled() and w1f.requires_grad):
         return w1f.unbind(0), terms, None

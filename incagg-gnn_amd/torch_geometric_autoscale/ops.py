@@ -374,6 +374,71 @@ def tn_finish(parts: Tensor, a_tail: Optional[Tensor], b_tail: Optional[Tensor],
     return out
 
 
+def column_sums(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """``x.sum(0)`` of a tall ``[rows, width]`` matrix (incagg_column_sums_f32): bias gradients.
+    Two launches, fixed summation order."""
+    _need_cuda(x, "x")
+    _rows_f32(x, "x")
+    rows, width = x.shape
+    if out is None:
+        out = torch.empty(width, dtype=torch.float32, device=x.device)
+    elif out.shape != (width,) or out.dtype != torch.float32 or not out.is_contiguous() \
+            or out.device != x.device:
+        raise ValueError("out must be a contiguous [width] float32 tensor on the device of x")
+    L = lib()
+    need = L.incagg_column_sums_ws_floats(rows, width)
+    check(need)
+    ws = torch.empty(max(int(need), 1), dtype=torch.float32, device=x.device)
+    with _on_device(x.device):
+        check(L.incagg_column_sums_f32(_ptr(x), _ld(x), rows, width, _ptr(ws), ws.numel(),
+                                       _ptr(out), _stream_of(x.device)))
+    return out
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        rows, classes = logits.shape
+        L = lib()
+        ws = torch.empty(int(L.incagg_softmax_xent_ws_floats(rows)), dtype=torch.float32,
+                         device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        with _on_device(logits.device):
+            check(L.incagg_softmax_xent_forward_f32(
+                _ptr(logits), _ld(logits), _ptr(labels), rows, classes, _ptr(ws), ws.numel(),
+                _ptr(loss), _stream_of(logits.device)))
+        ctx.save_for_backward(logits, labels, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, labels, ws = ctx.saved_tensors
+        rows, classes = logits.shape
+        dloss = dloss.contiguous()
+        dlogits = torch.empty((rows, classes), dtype=torch.float32, device=logits.device)
+        with _on_device(logits.device):
+            check(lib().incagg_softmax_xent_backward_f32(
+                _ptr(logits), _ld(logits), _ptr(labels), rows, classes, _ptr(ws), _ptr(dloss),
+                _ptr(dlogits), classes, _stream_of(logits.device)))
+        return dlogits, None
+
+
+def softmax_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
+    """Mean softmax cross entropy of ``logits`` [rows, classes] against int64 ``labels`` [rows]
+    -- ``torch.nn.CrossEntropyLoss()`` with its defaults (main.py:60,78) -- as two launches
+    forward and one backward (incagg_softmax_xent_*_f32).  Labels outside ``[0, classes)`` are
+    reported by ``check_device_errors``."""
+    _need_cuda(logits, "logits")
+    _rows_f32(logits, "logits")
+    if labels.dtype != torch.int64 or labels.dim() != 1 or labels.numel() != logits.size(0) \
+            or labels.device != logits.device or not labels.is_contiguous():
+        raise ValueError("labels must be a contiguous int64 vector with one entry per row, on "
+                         "the device of the logits")
+    if logits.size(0) < 1:
+        raise ValueError("no rows")
+    return _SoftmaxXent.apply(logits, labels)
+
+
 # --------------------------------------------------------------------------- History rows
 def _device_visible(t: Tensor) -> bool:
     return t.is_cuda or t.is_pinned()

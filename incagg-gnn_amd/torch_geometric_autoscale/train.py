@@ -28,6 +28,8 @@ from . import models
 from .data import gcn_norm, get_data
 from .loader import DeviceSubgraphLoader, EvalSubgraphLoader, SubgraphLoader
 from .metis import load_partition, metis, permute
+from .nn import CrossEntropyLoss
+from .optim import Adam
 from .utils import compute_micro_f1, dropout
 
 log = logging.getLogger("incagg.train")
@@ -202,7 +204,7 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
         data.adj_t = gcn_norm(data.adj_t, add_self_loops=False)
     if data.adj_t.device().type != "cpu":
         data.adj_t = data.adj_t.to("cpu")
-    criterion = torch.nn.CrossEntropyLoss() if data.y.dim() == 1 else torch.nn.BCEWithLogitsLoss()
+    criterion = CrossEntropyLoss() if data.y.dim() == 1 else torch.nn.BCEWithLogitsLoss()
 
     vr = bool(conf["VR_update"])
     loader_data = data.__class__(**{k: v for k, v in data if k != "ptr"})
@@ -230,12 +232,16 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
     model = GNN(num_nodes=data.num_nodes, in_channels=in_channels, out_channels=out_channels,
                 pool_size=params.get("pool_size"), buffer_size=buffer_size, device=hist_dev,
                 **arch).to(device)
-    optimizer = torch.optim.Adam([                                                # main.py:196-201
-        dict(params=model.reg_modules.parameters(),
+    groups = [                                                                    # main.py:196-201
+        dict(params=list(model.reg_modules.parameters()),
              weight_decay=params.get("reg_weight_decay", 0.0)),
-        dict(params=model.nonreg_modules.parameters(),
+        dict(params=list(model.nonreg_modules.parameters()),
              weight_decay=params.get("nonreg_weight_decay", 0.0)),
-    ], lr=params.get("lr", 0.01), fused=device.type == "cuda")
+    ]
+    if device.type == "cuda":       # the same update, one launch per group
+        optimizer = Adam([g for g in groups if g["params"]], lr=params.get("lr", 0.01))
+    else:
+        optimizer = torch.optim.Adam(groups, lr=params.get("lr", 0.01))
     use_agg = bool(conf["use_aggregation"])
 
     def refresh():

@@ -243,6 +243,54 @@ int incagg_tn_finish_f32(const float *parts, int64_t n_parts, const float *a_tai
                          const float *b_tail, int64_t ldb, int64_t n_tail, int64_t m, int64_t n,
                          float *out, int64_t ldo, void *stream);
 
+/* Dense-side helpers of the training step around the aggregation (the reference calls
+ * torch.nn.functional / torch.optim for them, main.py:60-90; none of its own sources is
+ * replaced).  All of them only enqueue on `stream`, allocate nothing and can be recorded into a
+ * HIP graph.
+ *
+ * out[c] = sum_r x[r, c] over a tall [rows, width] matrix (bias gradients), two launches, fixed
+ * summation order.  ws: device fp32 scratch of >= incagg_column_sums_ws_floats(rows, width). */
+int64_t incagg_column_sums_ws_floats(int64_t rows, int64_t width);
+int incagg_column_sums_f32(const float *x, int64_t ldx, int64_t rows, int64_t width, float *ws,
+                           int64_t ws_floats, float *out, void *stream);
+
+/* Mean softmax cross entropy of logits [rows, classes] (ld) against int64 class labels -- the
+ * value of torch.nn.CrossEntropyLoss() with its defaults (main.py:60,78) -- and its gradient:
+ *   forward:  *loss = mean_r (log sum_c exp(logits[r, c]) - logits[r, label[r]]);  keeps the
+ *             per-row log-sum-exp in ws (>= incagg_softmax_xent_ws_floats(rows) device floats)
+ *   backward: dlogits[r, c] = *dloss * (softmax(logits[r])[c] - [c == label[r]]) / rows, from
+ *             the same logits, labels and ws; dloss is a device scalar.
+ * A label outside [0, classes) is reported (incagg_check_device_errors); its row counts as
+ * loss 0 / gradient 0.  No class weights, no ignore_index, no label smoothing. */
+int64_t incagg_softmax_xent_ws_floats(int64_t rows);
+int incagg_softmax_xent_forward_f32(const float *logits, int64_t ld, const int64_t *labels,
+                                    int64_t rows, int64_t classes, float *ws, int64_t ws_floats,
+                                    float *loss, void *stream);
+int incagg_softmax_xent_backward_f32(const float *logits, int64_t ld, const int64_t *labels,
+                                     int64_t rows, int64_t classes, const float *ws,
+                                     const float *dloss, float *dlogits, int64_t ldd,
+                                     void *stream);
+
+/* One Adam step (torch.optim.Adam's update, main.py:160-165: no amsgrad, weight_decay added to
+ * the gradient) over a list of parameter tensors in ONE launch per 24 tensors:
+ *   g' = g + weight_decay p;  m += (g' - m)(1 - beta1);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = *step + 1.
+ * Every tensor has its own step count (device fp32, starts at 0; as in torch, a tensor that is
+ * left out of a call does not age), read and advanced on the device, so a recorded launch keeps
+ * counting when replayed; arrivals: a device int32 that is 0 between calls.  segs: HOST array;
+ * entries with n == 0 are skipped. */
+typedef struct incagg_adam_segment {
+  float *p;        /* parameters, updated in place */
+  const float *g;  /* gradients */
+  float *m;        /* first moments */
+  float *v;        /* second moments */
+  float *step;     /* steps taken so far */
+  int64_t n;
+} incagg_adam_segment;
+int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int32_t *arrivals,
+                         void *stream);
+
 /* ------------------------------------------------------------------ History rows
  * out[k,:] = emb[n_id[k],:]            (History.pull, history.py:33-39; the
  * gathered half of read_async, csrc/cuda/async_cuda.cu:95-110).

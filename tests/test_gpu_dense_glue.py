@@ -1,0 +1,148 @@
+"""Dense-side helpers of the training step (column sums, mean softmax cross entropy, Adam) against
+torch's own operators -- the ones the reference calls (main.py:60-90,160-165).  fp32 results
+within rounding of the fp64 / torch values; tolerances written at every comparison."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from torch_geometric_autoscale import ops
+    return ops
+
+
+@pytest.mark.parametrize("rows,width,pitch", [(128064, 256, 288), (16326, 47, 48), (16326, 47, 47),
+                                              (5, 3, 3), (1, 256, 256), (100003, 100, 100),
+                                              (70000, 300, 304), (4097, 1, 1)])
+def test_column_sums_match_fp64(ops, dev, rows, width, pitch):
+    g = torch.Generator(device=dev).manual_seed(rows + width)
+    base = torch.randn(rows, pitch, device=dev, generator=g)
+    x = base[:, :width]
+    got = ops.column_sums(x)
+    want = x.double().sum(0)
+    # sums of `rows` standard normals are ~ sqrt(rows) large: every add rounds at that size
+    tol = 1e-4 + 3e-6 * np.sqrt(rows)
+    assert got.shape == (width,)
+    assert float((got.double() - want).abs().max()) <= tol
+    # fixed summation order: the same bits every time
+    assert torch.equal(got, ops.column_sums(x))
+
+
+@pytest.mark.parametrize("rows,classes,pitch", [(16326, 47, 48), (16326, 47, 47), (1, 41, 41),
+                                                (5, 172, 176), (333, 1000, 1000), (4099, 2, 2)])
+def test_softmax_cross_entropy_matches_torch(ops, dev, rows, classes, pitch):
+    from torch_geometric_autoscale import _lib
+    g = torch.Generator(device=dev).manual_seed(rows * 7 + classes)
+    base = (torch.randn(rows, pitch, device=dev, generator=g) * 3).requires_grad_()
+    y = torch.randint(0, classes, (rows,), device=dev, generator=g)
+    logits = base[:, :classes]
+    loss = ops.softmax_cross_entropy(logits, y)
+    (loss * 1.7).backward()
+    got_grad = base.grad[:, :classes].clone()
+    ref_in = logits.detach().double().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(ref_in, y)
+    (ref * 1.7).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+    assert float((got_grad.double() - ref_in.grad).abs().max()) <= 1e-6 / rows + 1e-5 * float(
+        ref_in.grad.abs().max())
+    assert float(base.grad[:, classes:].abs().sum()) == 0.0       # padding columns untouched
+    _lib.check_device_errors()
+
+
+def test_softmax_cross_entropy_reports_bad_labels(ops, dev):
+    from torch_geometric_autoscale import _lib
+    logits = torch.randn(6, 5, device=dev, requires_grad=True)
+    y = torch.tensor([0, 4, 5, 1, -1, 2], device=dev)
+    loss = ops.softmax_cross_entropy(logits, y)
+    loss.backward()
+    with pytest.raises(RuntimeError):
+        _lib.check_device_errors()
+    good = [0, 1, 3, 5]
+    ref = torch.nn.functional.cross_entropy(logits.detach()[good], y[good], reduction="sum") / 6
+    assert abs(float(loss.detach()) - float(ref)) <= 1e-6
+    assert float(logits.grad[[2, 4]].abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        ops.softmax_cross_entropy(logits, y[:3])
+    with pytest.raises(ValueError):
+        ops.softmax_cross_entropy(logits, y.int())
+    _lib.check_device_errors()
+
+
+def _twin_params(dev, shapes, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ours = [torch.randn(s, device=dev, generator=g).requires_grad_() for s in shapes]
+    theirs = [p.detach().clone().requires_grad_() for p in ours]
+    return ours, theirs
+
+
+def _set_grads(params_a, params_b, gen, skip=()):
+    for i, (a, b) in enumerate(zip(params_a, params_b)):
+        if i in skip:
+            a.grad = b.grad = None
+            continue
+        gr = torch.randn(a.shape, device=a.device, generator=gen)
+        a.grad, b.grad = gr.clone(), gr.clone()
+
+
+def test_adam_matches_torch(dev):
+    from torch_geometric_autoscale.optim import Adam
+    shapes = [(256, 256), (47,), (256, 100), (1,), (3, 5), (12032,)] + [(17, 9)] * 25
+    ours, theirs = _twin_params(dev, shapes, 0)
+    groups = lambda ps: [dict(params=ps[:3], weight_decay=5e-4), dict(params=ps[3:], weight_decay=0.0)]
+    opt = Adam(groups(ours), lr=1e-2)
+    ref = torch.optim.Adam(groups(theirs), lr=1e-2)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for it in range(6):
+        _set_grads(ours, theirs, gen, skip=(4,) if it % 2 else ())
+        opt.step()
+        ref.step()
+    for a, b in zip(ours, theirs):
+        # same formulas in fp32; torch evaluates the bias corrections in double on the host
+        assert float((a - b).abs().max()) <= 2e-6 + 1e-5 * float(b.abs().max())
+    assert [float(opt.state[p]["step"]) for p in ours[:6]] == [6.0, 6.0, 6.0, 6.0, 3.0, 6.0]
+    assert int(opt.param_groups[0]["_arrivals"]) == 0
+    sd = opt.state_dict()
+    opt2 = Adam(groups([p.detach().clone().requires_grad_() for p in ours]), lr=1e-2)
+    opt2.load_state_dict(sd)
+    assert float(opt2.state[opt2.param_groups[1]["params"][1]]["step"]) == 3.0
+    assert torch.equal(opt2.state[opt2.param_groups[0]["params"][0]]["exp_avg"],
+                       opt.state[ours[0]]["exp_avg"])
+    opt.zero_grad()
+    assert all(p.grad is None for p in ours)
+    with pytest.raises(TypeError):
+        Adam([torch.zeros(3, requires_grad=True)])
+
+
+def test_adam_counts_steps_inside_a_replayed_graph(dev):
+    """The step count lives on the device: replays of ONE recorded step advance it."""
+    from torch_geometric_autoscale.optim import Adam
+    ours, theirs = _twin_params(dev, [(300, 7), (64,)], 3)
+    opt, ref = Adam(ours, lr=3e-3), torch.optim.Adam(theirs, lr=3e-3)
+    grads = [torch.randn(p.shape, device=dev) for p in ours]
+    for p, q, g in zip(ours, theirs, grads):
+        p.grad, q.grad = g, g.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step()                      # warm-up on the capture stream
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    steps = int(float(opt.state[ours[0]]["step"]))
+    assert steps == 4                   # 1 eager + 3 replays (recording itself runs nothing)
+    for _ in range(steps):
+        ref.step()
+    for a, b in zip(ours, theirs):
+        assert float((a - b).abs().max()) <= 2e-6 + 1e-5 * float(b.abs().max())
