@@ -113,6 +113,53 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *x, long long l
   if (c + 3 < width) o[3] = (a.w + b.w) + (d.w + e.w);
 }
 
+// Second pass: few rows (the partial sums), so 64 threads share a group of 16 columns -- thread
+// (r, q) adds rows r, r + 64, ... of column quad q -- and meet in LDS.
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *x, long long ldx, int rows,
+                                                            int width, float *out, int vec) {
+  __shared__ float4 part[64][4];
+  const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + q * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = rl; r < rows; r += 64) {
+    const float *p = x + (long long)r * ldx + c;
+    if (vec) {
+      if (c < width) {
+        const float4 a = *reinterpret_cast<const float4 *>(p);
+        acc.x += a.x;
+        acc.y += a.y;
+        acc.z += a.z;
+        acc.w += a.w;
+      }
+    } else {
+      if (c < width) acc.x += p[0];
+      if (c + 1 < width) acc.y += p[1];
+      if (c + 2 < width) acc.z += p[2];
+      if (c + 3 < width) acc.w += p[3];
+    }
+  }
+  part[rl][q] = acc;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if (rl < o) {
+      const float4 b = part[rl + o][q];
+      float4 a = part[rl][q];
+      a.x += b.x;
+      a.y += b.y;
+      a.z += b.z;
+      a.w += b.w;
+      part[rl][q] = a;
+    }
+    __syncthreads();
+  }
+  if (rl != 0) return;
+  const float4 a = part[0][q];
+  if (c < width) out[c] = a.x;
+  if (c + 1 < width) out[c + 1] = a.y;
+  if (c + 2 < width) out[c + 2] = a.z;
+  if (c + 3 < width) out[c + 3] = a.w;
+}
+
 static inline int colsum_rows_per_block(long long rows) {
   return (int)std::max<long long>(64, (rows + 1023) / 1024);  // at most 1024 partial rows
 }
@@ -194,8 +241,9 @@ __global__ __launch_bounds__(256) void xent_backward_kernel(const float *logits,
 // torch.optim.Adam's update (no amsgrad, no maximize): g' = g + wd p; m += (g' - m)(1 - b1);
 // v = b2 v + (1 - b2) g'^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), with
 // t = *step + 1, every tensor's own count, read from device memory (the launch can sit in a HIP
-// graph); the workgroup that finishes last stores the counts back.  Workgroup b handles 1024
-// consecutive elements of ONE tensor.
+// graph) and advanced by a one-wave launch behind it (counting arrivals on one address to find
+// the last workgroup costs more: ~1000 same-address atomics take 20 us).  Workgroup b handles
+// 1024 consecutive elements of ONE tensor.
 constexpr int kAdamSegments = 24;
 struct AdamTable {
   float *p[kAdamSegments];
@@ -208,13 +256,10 @@ struct AdamTable {
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, int n_seg, float lr, float b1,
-                                                   float b2, float eps, float wd, int *arrivals) {
-  __shared__ float s_step;
+                                                   float b2, float eps, float wd) {
   int seg = 0;
   while (seg + 1 < n_seg && (int)blockIdx.x >= t.first_block[seg + 1]) seg++;  // scalar
-  if (threadIdx.x == 0) s_step = *t.step[seg];
-  __syncthreads();
-  const float s = s_step, tt = s + 1.f;
+  const float tt = *t.step[seg] + 1.f;
   const int n = t.n[seg];
   const int i0 = ((int)blockIdx.x - t.first_block[seg]) * 1024 + (int)threadIdx.x * 4;
   const float bc1 = 1.f - powf(b1, tt), bc2_sqrt = sqrtf(1.f - powf(b2, tt));
@@ -243,24 +288,16 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, int n_seg,
   } else {
     for (int i = i0; i < min(i0 + 4, n); i++) one(p[i], g[i], m[i], v[i]);
   }
-  // Every thread of this workgroup has its copy of the old step count (through LDS, above).
-  // The arrival's operand depends on that value, so the count cannot be issued ahead of the
-  // read: when the last workgroup arrives, nobody needs the old counts any more.
-  __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int one_more = 1 + (__float_as_int(s) & 0);
-    s_last = atomicAdd(arrivals, one_more) == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if ((int)threadIdx.x < n_seg) {
-    // (tensors may share a counter: written once, by the first segment that names it)
-    bool first = true;
-    for (int k = 0; k < (int)threadIdx.x; k++) first = first && t.step[k] != t.step[threadIdx.x];
-    if (first) *t.step[threadIdx.x] += 1.f;
-  }
-  if (threadIdx.x == 0) atomicExch(arrivals, 0);
+}
+
+// Advances the step counts of one launch's tensors, after that launch (a counter shared by
+// several tensors is advanced once, by the first segment that names it).
+__global__ void adam_bump_kernel(const AdamTable t, int n_seg) {
+  const int k = threadIdx.x;
+  if (k >= n_seg) return;
+  for (int j = 0; j < k; j++)
+    if (t.step[j] == t.step[k]) return;
+  *t.step[k] += 1.f;
 }
 
 }  // namespace incagg
@@ -291,8 +328,8 @@ extern "C" int incagg_column_sums_f32(const float *x, int64_t ldx, int64_t rows,
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)n_part, col_blocks), dim3(256), 0, stream, x, ldx,
                      (int)rows, (int)width, rpb, ws, width, vec);
   INCAGG_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(colsum_kernel, dim3(1, col_blocks), dim3(256), 0, stream, ws, width, n_part,
-                     (int)width, n_part, out, width, (int)(aligned16(ws) && width % 4 == 0));
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((width + 15) / 16)), dim3(256), 0, stream,
+                     ws, width, n_part, (int)width, out, (int)(aligned16(ws) && width % 4 == 0));
   INCAGG_HIP_TRY(hipGetLastError());
   return INCAGG_OK;
 }
@@ -344,9 +381,8 @@ extern "C" int incagg_softmax_xent_backward_f32(const float *logits, int64_t ld,
 
 extern "C" int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float lr,
                                     float beta1, float beta2, float eps, float weight_decay,
-                                    int32_t *arrivals, void *stream_) {
+                                    void *stream_) {
   INCAGG_REQUIRE(n_segs >= 0 && (n_segs == 0 || segs), "bad segment list");
-  INCAGG_REQUIRE(arrivals, "null arrival counter");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   // launches of up to kAdamSegments tensors each
   int64_t first = 0;
@@ -374,7 +410,9 @@ extern "C" int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_s
     first = i;
     if (k == 0) break;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, k, lr, beta1,
-                       beta2, eps, weight_decay, arrivals);
+                       beta2, eps, weight_decay);
+    INCAGG_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, stream, t, k);
     INCAGG_HIP_TRY(hipGetLastError());
   }
   return INCAGG_OK;

@@ -42,7 +42,7 @@ SIGNATURES = {
     "incagg_softmax_xent_ws_floats": (_i64, [_i64]),
     "incagg_softmax_xent_forward_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "incagg_softmax_xent_backward_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
-    "incagg_adam_step_f32": (_int, [_vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "incagg_adam_step_f32": (_int, [_vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
     "incagg_gather_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "incagg_scatter_rows_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "incagg_copy_row_chunks_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp,

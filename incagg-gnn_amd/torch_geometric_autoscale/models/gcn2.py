@@ -8,7 +8,7 @@ from torch.nn import BatchNorm1d, ModuleList
 import torch
 
 from .. import ops
-from ..nn import GCN2Conv, RowsLinear, embed_relu, gcn2_batched_terms
+from ..nn import GCN2Conv, RowsLinear, embed_relu, gcn2_batched_terms, relu_into
 from .base import ScalableGNN
 
 
@@ -95,7 +95,9 @@ class GCN2(ScalableGNN):
         if state is not None and state.get('defer_relu') and layer < self.num_layers - 1:
             state['relu_deferred'] = True      # applied by the next aggregation and the push
             return h
-        h = h.relu_()
+        blocks = None if state is None else state.get('grad_blocks')
+        # (the last layer's gradient goes where the wide x_0 GEMMs of the backward pass read it)
+        h = relu_into(h, blocks[layer] if blocks and layer == self.num_layers - 1 else None)
         if layer == self.num_layers - 1:
             h = F.dropout(h, p=self.dropout, training=self.training)
             h = self.lins[1](h)

@@ -226,6 +226,33 @@ class _Layers(torch.autograd.Function):
         return gs, None
 
 
+class _ReluInPlace(torch.autograd.Function):
+    """``h.relu_()`` whose backward writes the gated gradient straight into ``grad_out`` (a
+    matrix of h's shape, e.g. this layer's block of the side-by-side gradient stack) instead
+    of into a fresh matrix that would then be copied there."""
+
+    @staticmethod
+    def forward(ctx, h, grad_out):
+        ctx.mark_dirty(h)
+        h.relu_()
+        ctx.save_for_backward(h)
+        ctx.grad_out = grad_out
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        h, = ctx.saved_tensors
+        return torch.ops.aten.threshold_backward.grad_input(g, h, 0, grad_input=ctx.grad_out), None
+
+
+def relu_into(h: Tensor, grad_out: Optional[Tensor]) -> Tensor:
+    """In-place relu; ``grad_out``: where its backward should leave the gradient of ``h``."""
+    if grad_out is None or not (torch.is_grad_enabled() and h.requires_grad) \
+            or grad_out.shape != h.shape:
+        return h.relu_()
+    return _ReluInPlace.apply(h, grad_out)
+
+
 class _FoldedSideBySide(torch.autograd.Function):
     """``[C, L*C]`` matrix whose column block l is ``const_l + scale_l * stack[l]`` (the folded
     second weights of all layers laid out for ONE wide GEMM), from the ``[L, C, C]`` stack of

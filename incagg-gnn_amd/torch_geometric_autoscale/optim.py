@@ -4,8 +4,8 @@ launch over all parameters of a group (incagg_adam_step_f32).
 torch's fused multi-tensor kernel walks the tensors in chunks of 65 536 elements: the ~1 M
 parameters of the models here give it 20 workgroups (43 us per step on MI355X, plus a launch that
 advances the step counters); this one gives every 1 024 elements a workgroup.  The step counts
-(one per parameter, as in torch) live on the device and are advanced by the launch itself, so a
-step recorded into a HIP graph keeps counting when it is replayed.
+(one per parameter, as in torch) live on the device and are advanced there, so a step recorded
+into a HIP graph keeps counting when it is replayed.
 """
 import ctypes
 from typing import Iterable, Union
@@ -62,8 +62,6 @@ class Adam:
                                  "exp_avg_sq": flat[sum(sizes) + off:sum(sizes) + off + p.numel()]
                                  .view_as(p)}
                 off += n
-            # the launch's arrival counter (0 between launches)
-            group["_arrivals"] = torch.zeros((), dtype=torch.int32, device=dev)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for group in self.param_groups:
@@ -99,12 +97,11 @@ class Adam:
             with ops._on_device(self.device):
                 _lib.check(L.incagg_adam_step_f32(
                     ctypes.addressof(segs), len(with_grad), group["lr"], b1, b2, group["eps"],
-                    group["weight_decay"], group["_arrivals"].data_ptr(),
-                    ops._stream_of(self.device)))
+                    group["weight_decay"], ops._stream_of(self.device)))
 
     def state_dict(self) -> dict:
         return {"param_groups": [{k: (v.clone() if isinstance(v, Tensor) else v)
-                                  for k, v in g.items() if k not in ("params", "_arrivals")}
+                                  for k, v in g.items() if k != "params"}
                                  for g in self.param_groups],
                 "state": [[{k: v.clone() for k, v in self.state[p].items()} for p in g["params"]]
                           for g in self.param_groups]}

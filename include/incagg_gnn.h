@@ -272,13 +272,13 @@ int incagg_softmax_xent_backward_f32(const float *logits, int64_t ld, const int6
                                      void *stream);
 
 /* One Adam step (torch.optim.Adam's update, main.py:160-165: no amsgrad, weight_decay added to
- * the gradient) over a list of parameter tensors in ONE launch per 24 tensors:
+ * the gradient) over a list of parameter tensors in ONE launch per 24 tensors (+ a one-wave
+ * launch that advances their step counts):
  *   g' = g + weight_decay p;  m += (g' - m)(1 - beta1);  v = beta2 v + (1 - beta2) g'^2;
  *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = *step + 1.
  * Every tensor has its own step count (device fp32, starts at 0; as in torch, a tensor that is
  * left out of a call does not age), read and advanced on the device, so a recorded launch keeps
- * counting when replayed; arrivals: a device int32 that is 0 between calls.  segs: HOST array;
- * entries with n == 0 are skipped. */
+ * counting when replayed.  segs: HOST array; entries with n == 0 are skipped. */
 typedef struct incagg_adam_segment {
   float *p;        /* parameters, updated in place */
   const float *g;  /* gradients */
@@ -288,8 +288,7 @@ typedef struct incagg_adam_segment {
   int64_t n;
 } incagg_adam_segment;
 int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float lr, float beta1,
-                         float beta2, float eps, float weight_decay, int32_t *arrivals,
-                         void *stream);
+                         float beta2, float eps, float weight_decay, void *stream);
 
 /* ------------------------------------------------------------------ History rows
  * out[k,:] = emb[n_id[k],:]            (History.pull, history.py:33-39; the

@@ -10,7 +10,7 @@ skip = int(sys.argv[3]) if len(sys.argv) > 3 else 11
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # steps end with the optimizer's kernel (+ its step-counter increment)
-ends = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "FusedAdam" in r["Kernel_Name"]]
 k = len(ends) - skip - 3          # a step of the timed region (the eager pass comes after it)
 step = rows[ends[k - 1] + 1:ends[k] + 1]
 t0 = int(step[0]["Start_Timestamp"])
