@@ -53,7 +53,15 @@ class StepGraphs:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=self.pool, stream=self.stream,
                               capture_error_mode=capture_error_mode):
-            fn()
+            try:
+                fn()
+            except BaseException:
+                # ending a broken recording can itself fail (or crash): show the cause first
+                import sys
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                sys.stderr.flush()
+                raise
         self.graphs[key] = graph
 
     def replay(self, key: Hashable) -> None:
