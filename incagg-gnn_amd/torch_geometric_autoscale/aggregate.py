@@ -30,7 +30,7 @@ def _as_rows(x: Tensor) -> Tensor:
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_halo, add, adj, reduce, scale, add_scale, halo_ids, relu_x=False,
-                gate_grad=False, grad_out=None):
+                gate_grad=False, grad_out=None, out=None):
         rowptr, col, val = adj.device_csr()
         n_cols = adj.size(1)
         if halo_ids is not None:
@@ -40,7 +40,7 @@ class _SpMM(torch.autograd.Function):
             plan = adj.plan_edges_in_place(halo_ids, x.size(0))
         else:
             plan = adj.plan_edges()
-        y = ops.spmm_csr(rowptr, col, val, x, n_cols, reduce, scale, add, add_scale,
+        y = ops.spmm_csr(rowptr, col, val, x, n_cols, reduce, scale, add, add_scale, out=out,
                          x_halo=x_halo, plan=plan, relu_x=relu_x)
         # relu_x: x holds pre-activations and this call consumes relu(x); gate_grad: x IS the
         # output of a relu whose backward the caller leaves to this call.  Either way the
@@ -79,7 +79,7 @@ class _SpMM(torch.autograd.Function):
                                               n_cols, ctx.halo_rows)
         if ctx.has_add and ctx.needs_input_grad[2]:
             dadd = dy * ctx.add_scale
-        return dx, dhalo, dadd, None, None, None, None, None, None, None, None
+        return dx, dhalo, dadd, None, None, None, None, None, None, None, None, None
 
 
 class _IncAgg(torch.autograd.Function):
@@ -131,7 +131,7 @@ def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
          add: Optional[Tensor] = None, add_scale: float = 0.0,
          x_halo: Optional[Tensor] = None, halo_ids: Optional[Tensor] = None,
          relu_x: bool = False, gate_grad: bool = False,
-         grad_out: Optional[Tensor] = None) -> Tensor:
+         grad_out: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """``adj @ x`` / ``spmm(adj, x, reduce)`` with an optional fused ``+ add_scale * add``.
 
     ``x_halo``: the source rows are ``[x ; x_halo]`` without concatenating them -- ``x``
@@ -148,7 +148,12 @@ def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
     ``gate_grad``: ``x`` is the output of a relu whose backward is folded into this call's
     backward (the gradient returned is already zeroed where ``x <= 0``).
     ``grad_out``: a [rows of x, width] buffer (rows may be strided) the backward pass writes the
-    gradient w.r.t. ``x`` into, instead of a matrix of its own."""
+    gradient w.r.t. ``x`` into, instead of a matrix of its own.
+    ``out`` (outside autograd only): the [rows of adj, width] matrix the result is written into,
+    e.g. the batch's rows of a History table of aggregates."""
+    if out is not None and torch.is_grad_enabled() and (
+            x.requires_grad or (add is not None and add.requires_grad)):
+        raise RuntimeError("out= is for calls outside autograd")
     if reduce not in ("sum", "add", "mean"):
         raise ValueError(f"unsupported reduce '{reduce}'")
     x = _as_rows(x)
@@ -159,7 +164,7 @@ def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
     if halo_ids is not None and x_halo is None:
         raise ValueError("halo_ids needs the table to read from (x_halo)")
     return _SpMM.apply(x, x_halo, add, adj, "mean" if reduce == "mean" else "sum", float(scale),
-                       float(add_scale), halo_ids, bool(relu_x), bool(gate_grad), grad_out)
+                       float(add_scale), halo_ids, bool(relu_x), bool(gate_grad), grad_out, out)
 
 
 def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,

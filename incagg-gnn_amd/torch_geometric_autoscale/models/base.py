@@ -175,8 +175,9 @@ class ScalableGNN(torch.nn.Module):
         return unweighted(adj_t) if self.agg_reduce == "mean" else adj_t
 
     def _aggregate(self, adj_t: SparseTensor, x: Tensor, halo: Optional[Tensor] = None,
-                   halo_ids: Optional[Tensor] = None) -> Tensor:
-        return spmm(self._adj(adj_t), x, reduce=self.agg_reduce, x_halo=halo, halo_ids=halo_ids)
+                   halo_ids: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+        return spmm(self._adj(adj_t), x, reduce=self.agg_reduce, x_halo=halo, halo_ids=halo_ids,
+                    out=out)
 
     def _drop(self, x: Tensor) -> Tensor:
         p = getattr(self, "dropout", 0.0)
@@ -641,9 +642,19 @@ class ScalableGNN(torch.nn.Module):
 
         def run_layer(i, x, adj_t, batch_size, offset, count, state, halo=None, halo_ids=None):
             offset = self._local(offset)
-            agg = (self._aggregate(adj_t, x, halo, halo_ids) if use_aggregation
+            # a batch that is ONE range of table rows: the aggregation writes its result where
+            # the table of aggregates keeps it (no push of its own)
+            dest = None
+            if (with_aggregates and use_aggregation and pool_ag is None and count.numel() == 1
+                    and x.is_cuda and x.dtype == torch.float32):
+                tab = self.histories_ag[i].emb
+                if _same_device(tab.device, x.device) and tab.size(1) == x.size(1) \
+                        and tab.dtype == x.dtype:
+                    o = int(offset[0])
+                    dest = tab[o:o + batch_size]
+            agg = (self._aggregate(adj_t, x, halo, halo_ids, out=dest) if use_aggregation
                    else x[:batch_size])
-            if with_aggregates:
+            if with_aggregates and dest is None:
                 self._push_rows(self.histories_ag[i].emb, agg, offset, count, pool_ag)
             # a relu that ends the layer is left to the push where the model allows it (every
             # later reader of these rows -- the next layer of the sweep, training steps --

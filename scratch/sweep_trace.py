@@ -10,7 +10,7 @@ f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-last = max(i for i, n in enumerate(names) if "FusedOptimizer" in n)
+last = max(i for i, n in enumerate(names) if "FusedOptimizer" in n or "adam_bump_kernel" in n)
 sw = rows[last + 1:]
 dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 print("sweep kernels", len(sw), "busy ms", sum(map(dur, sw)) / 1e6, "span ms",
