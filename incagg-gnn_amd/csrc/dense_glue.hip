@@ -27,9 +27,71 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const float *parts, int 
   out[i * ldo + j] = acc;
 }
 
+// The same for several products of one shape at once (the weight gradients of all layers of a
+// model, finished by ONE launch at the end of the backward pass instead of one launch per
+// layer): workgroup b works on product b / blocks_per_product; every product's slab partials
+// and remainder rows come from a pointer table.
+constexpr int kFinishBatch = 16;
+struct FinishTable {
+  const float *parts[kFinishBatch];
+  const float *a[kFinishBatch];
+  const float *b[kFinishBatch];
+  long long lda[kFinishBatch];
+  long long ldb[kFinishBatch];
+};
+
+__global__ __launch_bounds__(256) void tn_finish_batched_kernel(const FinishTable t, int n_parts,
+                                                                int n_tail, int m, int n,
+                                                                int blocks_per_product, float *out) {
+  const int l = blockIdx.x / blocks_per_product;
+  const long long idx = (long long)(blockIdx.x - l * blocks_per_product) * blockDim.x + threadIdx.x;
+  const long long mn = (long long)m * n;
+  if (idx >= mn) return;
+  const int i = (int)(idx / n), j = (int)(idx - (long long)i * n);
+  const float *p = t.parts[l] + idx;
+  float acc = 0.f;
+  for (int s = 0; s < n_parts; s++) acc += p[s * mn];
+  const float *a = t.a[l], *b = t.b[l];
+  const long long lda = t.lda[l], ldb = t.ldb[l];
+  for (int r = 0; r < n_tail; r++) acc += a[r * lda + i] * b[r * ldb + j];
+  out[l * mn + idx] = acc;
+}
+
 }  // namespace incagg
 
 using namespace incagg;
+
+extern "C" int incagg_tn_finish_batched_f32(const float *const *parts, int64_t n_batch,
+                                            int64_t n_parts, const float *const *a_tails,
+                                            const int64_t *lda, const float *const *b_tails,
+                                            const int64_t *ldb, int64_t n_tail, int64_t m, int64_t n,
+                                            float *out, void *stream) {
+  INCAGG_REQUIRE(m >= 0 && n >= 0 && n_parts >= 0 && n_tail >= 0 && n_batch >= 0, "negative size");
+  INCAGG_REQUIRE(m < INT_MAX && n < INT_MAX && m * n < (1ll << 40) && n_parts < INT_MAX &&
+                     n_tail < INT_MAX, "size out of range");
+  INCAGG_REQUIRE(n_batch <= kFinishBatch, "at most %d products per call", kFinishBatch);
+  if (m == 0 || n == 0 || n_batch == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(out && parts, "null output or parts");
+  FinishTable t{};
+  for (int64_t l = 0; l < n_batch; l++) {
+    INCAGG_REQUIRE(n_parts == 0 || parts[l], "null parts of product %lld", (long long)l);
+    t.parts[l] = parts[l];
+    if (n_tail == 0) continue;
+    INCAGG_REQUIRE(a_tails && b_tails && lda && ldb && a_tails[l] && b_tails[l] && lda[l] >= m &&
+                       ldb[l] >= n, "bad remainder rows of product %lld", (long long)l);
+    t.a[l] = a_tails[l];
+    t.b[l] = b_tails[l];
+    t.lda[l] = lda[l];
+    t.ldb[l] = ldb[l];
+  }
+  const long long per = (m * n + 255) / 256;
+  INCAGG_REQUIRE(per * n_batch < INT_MAX, "grid too large");
+  hipLaunchKernelGGL(tn_finish_batched_kernel, dim3((unsigned)(per * n_batch)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), t, (int)n_parts, (int)n_tail, (int)m, (int)n,
+                     (int)per, out);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
 
 extern "C" int incagg_tn_finish_f32(const float *parts, int64_t n_parts, const float *a_tail,
                                     int64_t lda, const float *b_tail, int64_t ldb, int64_t n_tail,

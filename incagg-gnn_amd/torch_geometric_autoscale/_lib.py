@@ -37,6 +37,7 @@ SIGNATURES = {
     "incagg_set_tuning": (_int, [_c.c_char_p, _int]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_tn_finish_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "incagg_tn_finish_batched_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "incagg_column_sums_ws_floats": (_i64, [_i64, _i64]),
     "incagg_column_sums_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "incagg_softmax_xent_ws_floats": (_i64, [_i64]),

@@ -38,7 +38,57 @@ def _slab_count(rows: int) -> int:
     return 8 if rows < 65536 else 32
 
 
-def _tn_product(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+class _DeferredProducts:
+    """The ``a_l^T @ b_l`` products of L layers (all of one shape) whose last step -- slab sum +
+    remainder rows -- is run for all layers by ONE launch once the last of them has been
+    started, into ``stack`` ([L, m, n]); a launch per layer costs 5-6 us each for a few
+    microseconds' worth of work."""
+
+    def __init__(self, stack: Tensor):
+        self.stack = stack
+        n_layers = stack.size(0)
+        self.parts, self.tails = [None] * n_layers, [None] * n_layers
+        self.pending = []
+
+    def slot(self, index: int) -> "_DeferredSlot":
+        return _DeferredSlot(self, index)
+
+    def add(self, index: int, a: Tensor, b: Tensor) -> Tensor:
+        """Starts product ``index`` (the batched GEMM over row slabs); its value is in
+        ``stack[index]`` after :meth:`finish`."""
+        rows = a.size(0)
+        slabs = _slab_count(rows)
+        k = (rows // slabs) * slabs
+        self.parts[index] = torch.bmm(a[:k].unflatten(0, (slabs, k // slabs)).transpose(1, 2),
+                                      b[:k].unflatten(0, (slabs, k // slabs)))
+        self.tails[index] = (a[k:], b[k:]) if k < rows else None
+        self.pending.append(index)
+        return self.stack[index]
+
+    def finish(self) -> None:
+        if not self.pending:
+            return
+        done = sorted(self.pending)
+        shapes = {(tuple(self.parts[i].shape), None if self.tails[i] is None
+                   else self.tails[i][0].size(0)) for i in done}
+        if done == list(range(self.stack.size(0))) and len(shapes) == 1 and len(done) <= 16:
+            ops.tn_finish_batched(self.parts, self.tails, self.stack)
+        else:
+            for i in done:
+                t = self.tails[i]
+                ops.tn_finish(self.parts[i], None if t is None else t[0],
+                              None if t is None else t[1], self.stack[i])
+        self.pending = []
+        self.parts = [None] * len(self.parts)
+        self.tails = [None] * len(self.tails)
+
+
+class _DeferredSlot:
+    def __init__(self, owner: _DeferredProducts, index: int):
+        self.owner, self.index = owner, index
+
+
+def _tn_product(a: Tensor, b: Tensor, out=None) -> Tensor:
     """``a^T @ b`` for tall operands ([rows, m], [rows, n], rows >> m, n): the shape of every
     weight gradient here.  A [m, n] output gives a GEMM only a handful of tiles while the
     reduction runs over 10^4..10^5 rows, so the rows are cut into slabs that run as one
@@ -47,9 +97,17 @@ def _tn_product(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     77 us with 32 slabs, 123 us with 8, 376 us as one GEMM.  Rows may be strided (slices of a
     wider matrix): nothing is copied."""
     rows = a.size(0)
+    direct = rows < 4096 or a.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1
+    if isinstance(out, _DeferredSlot):
+        # ``out``: a slot of _DeferredProducts -- the product is started here and finished,
+        # together with the other layers', by its owner
+        if a.is_cuda and a.dtype == torch.float32 and not direct:
+            return out.owner.add(out.index, a, b)
+        out = out.owner.stack[out.index]
+        return out.copy_(_tn_product(a, b))
     if out is not None and not (a.is_cuda and a.dtype == torch.float32 and rows >= 4096):
         out = None          # (only the finishing kernel writes where it is told to)
-    if rows < 4096 or a.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+    if direct:
         return a.t() @ b
     slabs = _slab_count(rows)
     k = (rows // slabs) * slabs
@@ -211,19 +269,21 @@ class _Layers(torch.autograd.Function):
     ``grad_stack[l]``) instead of copying every one of them into a fresh stack."""
 
     @staticmethod
-    def forward(ctx, stack, grad_stack):
-        ctx.grad_stack = grad_stack
+    def forward(ctx, stack, grad_stack, deferred=None):
+        ctx.grad_stack, ctx.deferred = grad_stack, deferred
         return tuple(t.data for t in stack.unbind(0))
 
     @staticmethod
     def backward(ctx, *grads):
         gs = ctx.grad_stack
+        if ctx.deferred is not None:    # every layer's product has been started by now
+            ctx.deferred.finish()
         for i, g in enumerate(grads):
             if g is None:
                 gs[i].zero_()
             elif g.data_ptr() != gs[i].data_ptr() or g.stride() != gs[i].stride():
                 gs[i].copy_(g)
-        return gs, None
+        return gs, None, None
 
 
 class _ReluInPlace(torch.autograd.Function):
@@ -497,8 +557,10 @@ def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
     if not (torch.is_grad_enabled() and w1f.requires_grad):
         return w1f.unbind(0), terms, None
     # the layers' weight gradients are written side by side by their producers
+    # (and finished together, by one launch, when the last layer's backward has run)
     dw1 = torch.empty_like(w1f)
-    return _Layers.apply(w1f, dw1), terms, dw1.unbind(0)
+    deferred = _DeferredProducts(dw1)
+    return _Layers.apply(w1f, dw1, deferred), terms, [deferred.slot(i) for i in range(n_layers)]
 
 
 class SAGEConv(torch.nn.Module):

@@ -374,6 +374,51 @@ def tn_finish(parts: Tensor, a_tail: Optional[Tensor], b_tail: Optional[Tensor],
     return out
 
 
+def tn_finish_batched(parts, tails, out: Tensor) -> Tensor:
+    """``out[l] = parts[l].sum(0) + a_l^T @ b_l`` for all l in one launch
+    (incagg_tn_finish_batched_f32).  ``parts``: L contiguous ``[slabs, m, n]`` tensors;
+    ``tails``: L pairs ``(a_l [r, m], b_l [r, n])`` of remainder rows (or L times ``None``);
+    ``out``: contiguous ``[L, m, n]``."""
+    n_batch = len(parts)
+    if n_batch == 0:
+        return out
+    _need_cuda(parts[0], "parts")
+    dev = parts[0].device
+    s_, m, n = parts[0].shape
+    for p in parts:
+        if p.shape != (s_, m, n) or p.dtype != torch.float32 or not p.is_contiguous() \
+                or p.device != dev:
+            raise ValueError("parts must be contiguous [slabs, m, n] float32 tensors of one shape")
+    if (tuple(out.shape) != (n_batch, m, n) or out.dtype != torch.float32
+            or not out.is_contiguous() or out.device != dev):
+        raise ValueError("out must be a contiguous [L, m, n] float32 tensor on the device of parts")
+    if len(tails) != n_batch:
+        raise ValueError("one pair of remainder rows per product")
+    r = 0 if tails[0] is None else tails[0][0].size(0)
+    p_ptr = (ctypes.c_void_p * n_batch)(*[_ptr(p) for p in parts])
+    a_ptr, b_ptr = (ctypes.c_void_p * n_batch)(), (ctypes.c_void_p * n_batch)()
+    lda, ldb = (ctypes.c_int64 * n_batch)(), (ctypes.c_int64 * n_batch)()
+    for l, pair in enumerate(tails):
+        if r == 0:
+            if pair is not None and pair[0].size(0) != 0:
+                raise ValueError("all products must have the same number of remainder rows")
+            continue
+        if pair is None:
+            raise ValueError("all products must have the same number of remainder rows")
+        a, b = pair
+        _rows_f32(a, "a_tail", dev)
+        _rows_f32(b, "b_tail", dev)
+        if a.shape != (r, m) or b.shape != (r, n):
+            raise ValueError("remainder rows must be [r, m] and [r, n], r the same everywhere")
+        a_ptr[l], b_ptr[l], lda[l], ldb[l] = _ptr(a), _ptr(b), _ld(a), _ld(b)
+    with _on_device(dev):
+        check(lib().incagg_tn_finish_batched_f32(
+            ctypes.addressof(p_ptr), n_batch, s_, ctypes.addressof(a_ptr), ctypes.addressof(lda),
+            ctypes.addressof(b_ptr), ctypes.addressof(ldb), r, m, n, _ptr(out),
+            _stream_of(dev)))
+    return out
+
+
 def column_sums(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """``x.sum(0)`` of a tall ``[rows, width]`` matrix (incagg_column_sums_f32): bias gradients.
     Two launches, fixed summation order."""

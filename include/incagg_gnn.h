@@ -242,6 +242,14 @@ int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, int64_t ldb
 int incagg_tn_finish_f32(const float *parts, int64_t n_parts, const float *a_tail, int64_t lda,
                          const float *b_tail, int64_t ldb, int64_t n_tail, int64_t m, int64_t n,
                          float *out, int64_t ldo, void *stream);
+/* The same for n_batch <= 16 products of one shape in ONE launch (the weight gradients of all
+ * layers, finished together at the end of the backward pass): out [n_batch, m, n] contiguous;
+ * parts / a_tails / b_tails / lda / ldb: HOST arrays with one entry per product (device
+ * pointers to its S contiguous [m, n] partials, to its R remainder rows, and their pitches). */
+int incagg_tn_finish_batched_f32(const float *const *parts, int64_t n_batch, int64_t n_parts,
+                                 const float *const *a_tails, const int64_t *lda,
+                                 const float *const *b_tails, const int64_t *ldb, int64_t n_tail,
+                                 int64_t m, int64_t n, float *out, void *stream);
 
 /* Dense-side helpers of the training step around the aggregation (the reference calls
  * torch.nn.functional / torch.optim for them, main.py:60-90; none of its own sources is

@@ -737,3 +737,39 @@ def test_tn_finish_matches_torch(ops, dev, shape):
     y = torch.randn(rows, n, device=dev, generator=g)
     ref = (x.double().t() @ y.double())
     assert torch.allclose(_tn_product(x, y).double(), ref, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("r", [0, 6])
+def test_tn_finish_batched_matches_torch(ops, dev, r):
+    """The last step of several weight-gradient products at once, and the deferred form of
+    nn._tn_product that uses it (one finishing launch for all layers)."""
+    from torch_geometric_autoscale.nn import _DeferredProducts, _tn_product
+    g = torch.Generator(device=dev).manual_seed(4 + r)
+    n_l, s_, m, n = 5, 8, 48, 36
+    parts = [torch.randn(s_, m, n, device=dev, generator=g) for _ in range(n_l)]
+    tails = [(torch.randn(9, m + 4, device=dev, generator=g)[:r, :m],
+              torch.randn(9, n + 12, device=dev, generator=g)[:r, :n]) if r else None
+             for _ in range(n_l)]
+    out = torch.full((n_l, m, n), float("nan"), device=dev)
+    ops.tn_finish_batched(parts, tails, out)
+    for l in range(n_l):
+        want = parts[l].double().sum(0)
+        if r:
+            want = want + tails[l][0].double().t() @ tails[l][1].double()
+        assert torch.allclose(out[l].double(), want, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops.tn_finish_batched(parts, tails[:-1], out)
+    # deferred products: rows that do (8 * 2000) / do not (16327) fill the slabs
+    rows = 16000 if r == 0 else 16327
+    xs = [torch.randn(rows, m, device=dev, generator=g) for _ in range(3)]
+    ys = [torch.randn(rows, n + 4, device=dev, generator=g)[:, :n] for _ in range(3)]
+    for which in ((0, 1, 2), (2, 0)):          # all layers (one launch) / a subset (one each)
+        stack = torch.full((3, m, n), float("nan"), device=dev)
+        deferred = _DeferredProducts(stack)
+        for l in which:
+            got = _tn_product(xs[l], ys[l], deferred.slot(l))
+            assert got.data_ptr() == stack[l].data_ptr()
+        deferred.finish()
+        for l in which:
+            ref = xs[l].double().t() @ ys[l].double()
+            assert torch.allclose(stack[l].double(), ref, rtol=1e-4, atol=2e-3)
