@@ -479,3 +479,188 @@ extern "C" int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_s
   }
   return INCAGG_OK;
 }
+
+// =====================================================================================
+// Element-wise passes of the dense side that torch runs as two launches or at half the
+// streaming rate, and the weight fold of the GCNII layers.
+// =====================================================================================
+namespace incagg {
+
+// x = max(x, 0) in place over [rows, width] (pitch ld).
+template <int VEC>
+__global__ __launch_bounds__(256) void relu_rows_kernel(float *x, long long ld, long long rows,
+                                                        int width) {
+  const int per_row = width / VEC;
+  const long long total = rows * per_row;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / per_row;
+    float *p = x + r * ld + (int)(i - r * per_row) * VEC;
+    if (VEC == 4) {
+      float4 v = *reinterpret_cast<float4 *>(p);
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+      *reinterpret_cast<float4 *>(p) = v;
+    } else {
+      *p = fmaxf(*p, 0.f);
+    }
+  }
+}
+
+// dst += src wherever gate > 0 (the backward of a relu added onto an existing gradient).
+template <int VEC>
+__global__ __launch_bounds__(256) void gate_add_rows_kernel(float *dst, long long ldd,
+                                                            const float *src, long long lds,
+                                                            const float *gate, long long ldg,
+                                                            long long rows, int width) {
+  const int per_row = width / VEC;
+  const long long total = rows * per_row;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / per_row;
+    const int c = (int)(i - r * per_row) * VEC;
+    float *d = dst + r * ldd + c;
+    const float *s = src + r * lds + c, *g = gate + r * ldg + c;
+    if (VEC == 4) {
+      float4 dv = *reinterpret_cast<float4 *>(d);
+      const float4 sv = *reinterpret_cast<const float4 *>(s);
+      const float4 gv = *reinterpret_cast<const float4 *>(g);
+      dv.x += gv.x > 0.f ? sv.x : 0.f;
+      dv.y += gv.y > 0.f ? sv.y : 0.f;
+      dv.z += gv.z > 0.f ? sv.z : 0.f;
+      dv.w += gv.w > 0.f ? sv.w : 0.f;
+      *reinterpret_cast<float4 *>(d) = dv;
+    } else {
+      *d += *g > 0.f ? *s : 0.f;
+    }
+  }
+}
+
+// GCNII with separate weights (models/gcn2.py:46-48 through PyG's GCN2Conv):
+//   out = (1 - alpha) (A x) ((1 - beta_l) I + beta_l W1_l) + alpha x_0 ((1 - beta_l) I + beta_l W2_l).
+// The identity parts are folded into the weights of all L layers by one launch:
+//   w1f[l]               = (1 - alpha) (beta_l W1_l + (1 - beta_l) I)         [L, C, C]
+//   w2cat[:, lC:(l+1)C]  = alpha (beta_l W2_l + (1 - beta_l) I)               [C, L C]
+// from ws = [W1_0 .. W1_{L-1}, W2_0 .. W2_{L-1}] ([2L, C, C]); the backward kernel maps the
+// gradients of w1f / w2cat back onto that stack.
+constexpr int kFoldLayers = 64;
+struct FoldBetas {
+  float beta[kFoldLayers];
+};
+
+__global__ __launch_bounds__(256) void fold_weights_kernel(const float *ws, int n_layers, int c,
+                                                           float alpha, const FoldBetas b,
+                                                           float *w1f, float *w2cat) {
+  const long long cc = (long long)c * c, half = n_layers * cc;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * half) return;
+  const bool second = idx >= half;
+  const long long k = second ? idx - half : idx;
+  const int l = (int)(k / cc), i = (int)((k - l * cc) / c), j = (int)(k - l * cc - (long long)i * c);
+  const float beta = b.beta[l];
+  const float v = (second ? alpha : 1.f - alpha) * (beta * ws[idx] + (i == j ? 1.f - beta : 0.f));
+  if (second)
+    w2cat[(long long)i * n_layers * c + (long long)l * c + j] = v;
+  else
+    w1f[k] = v;
+}
+
+__global__ __launch_bounds__(256) void fold_weights_backward_kernel(const float *dw1f,
+                                                                    const float *dw2cat,
+                                                                    int n_layers, int c, float alpha,
+                                                                    const FoldBetas b, float *dws) {
+  const long long cc = (long long)c * c, half = n_layers * cc;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * half) return;
+  const bool second = idx >= half;
+  const long long k = second ? idx - half : idx;
+  const int l = (int)(k / cc), i = (int)((k - l * cc) / c), j = (int)(k - l * cc - (long long)i * c);
+  const float g = second ? dw2cat[(long long)i * n_layers * c + (long long)l * c + j] : dw1f[k];
+  dws[idx] = (second ? alpha : 1.f - alpha) * b.beta[l] * g;
+}
+
+static inline bool rows_vec4_ok(const void *p, long long ld, long long width) {
+  return aligned16(p) && ld % 4 == 0 && width % 4 == 0;
+}
+
+}  // namespace incagg
+
+extern "C" int incagg_relu_rows_f32(float *x, int64_t ld, int64_t rows, int64_t width,
+                                    void *stream) {
+  INCAGG_REQUIRE(rows >= 0 && width >= 0 && width < INT_MAX, "bad size");
+  if (rows == 0 || width == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(x && ld >= width, "null pointer or ld < width");
+  const bool vec = rows_vec4_ok(x, ld, width);
+  const long long items = rows * (width / (vec ? 4 : 1));
+  const int blocks = (int)std::min<long long>((items + 255) / 256, 8192);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec)
+    hipLaunchKernelGGL((relu_rows_kernel<4>), dim3(blocks), dim3(256), 0, s, x, ld, rows, (int)width);
+  else
+    hipLaunchKernelGGL((relu_rows_kernel<1>), dim3(blocks), dim3(256), 0, s, x, ld, rows, (int)width);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds,
+                                        const float *gate, int64_t ldg, int64_t rows, int64_t width,
+                                        void *stream) {
+  INCAGG_REQUIRE(rows >= 0 && width >= 0 && width < INT_MAX, "bad size");
+  if (rows == 0 || width == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(dst && src && gate && ldd >= width && lds >= width && ldg >= width,
+                 "null pointer or a pitch below the width");
+  const bool vec = rows_vec4_ok(dst, ldd, width) && rows_vec4_ok(src, lds, width) &&
+                   rows_vec4_ok(gate, ldg, width);
+  const long long items = rows * (width / (vec ? 4 : 1));
+  const int blocks = (int)std::min<long long>((items + 255) / 256, 8192);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec)
+    hipLaunchKernelGGL((gate_add_rows_kernel<4>), dim3(blocks), dim3(256), 0, s, dst, ldd, src, lds,
+                       gate, ldg, rows, (int)width);
+  else
+    hipLaunchKernelGGL((gate_add_rows_kernel<1>), dim3(blocks), dim3(256), 0, s, dst, ldd, src, lds,
+                       gate, ldg, rows, (int)width);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+static int fold_args(int64_t n_layers, int64_t c, const float *beta, FoldBetas &b, long long &blocks) {
+  INCAGG_REQUIRE(n_layers >= 1 && n_layers <= kFoldLayers, "1..%d layers", kFoldLayers);
+  INCAGG_REQUIRE(c >= 1 && c <= 16384 && beta, "bad width or null beta");
+  for (int64_t l = 0; l < n_layers; l++) b.beta[l] = beta[l];
+  blocks = (2 * n_layers * c * c + 255) / 256;
+  INCAGG_REQUIRE(blocks < INT_MAX, "grid too large");
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_gcn2_fold_weights_f32(const float *ws, int64_t n_layers, int64_t c,
+                                            float alpha, const float *beta, float *w1f,
+                                            float *w2cat, void *stream) {
+  FoldBetas b{};
+  long long blocks = 0;
+  int rc = fold_args(n_layers, c, beta, b, blocks);
+  if (rc) return rc;
+  INCAGG_REQUIRE(ws && w1f && w2cat, "null pointer");
+  hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), ws, (int)n_layers, (int)c, alpha, b, w1f,
+                     w2cat);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_gcn2_fold_weights_backward_f32(const float *dw1f, const float *dw2cat,
+                                                     int64_t n_layers, int64_t c, float alpha,
+                                                     const float *beta, float *dws, void *stream) {
+  FoldBetas b{};
+  long long blocks = 0;
+  int rc = fold_args(n_layers, c, beta, b, blocks);
+  if (rc) return rc;
+  INCAGG_REQUIRE(dw1f && dw2cat && dws, "null pointer");
+  hipLaunchKernelGGL(fold_weights_backward_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dw1f, dw2cat, (int)n_layers, (int)c, alpha, b,
+                     dws);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}

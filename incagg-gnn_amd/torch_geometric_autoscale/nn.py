@@ -216,7 +216,10 @@ class _EmbedRelu(torch.autograd.Function):
         else:
             g = torch.ops.aten.threshold_backward(d_all.contiguous(), h, 0)   # new tensor
         if d_batch is not None:
-            g[:nb] += torch.ops.aten.threshold_backward(d_batch.contiguous(), h[:nb], 0)
+            if g.is_cuda and g.dtype == torch.float32 and d_batch.stride(-1) == 1:
+                ops.gate_add_rows_(g[:nb], d_batch, h[:nb])     # one launch instead of two
+            else:
+                g[:nb] += torch.ops.aten.threshold_backward(d_batch.contiguous(), h[:nb], 0)
         dx = g @ weight if ctx.needs_input_grad[0] else None
         dw = _tn_product(g, x) if ctx.needs_input_grad[1] else None
         db = _column_sums(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
@@ -294,7 +297,10 @@ class _ReluInPlace(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, grad_out):
         ctx.mark_dirty(h)
-        h.relu_()
+        if h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.stride(1) == 1:
+            ops.relu_rows_(h)       # (twice the rate of torch's in-place clamp on MI355X)
+        else:
+            h.relu_()
         ctx.save_for_backward(h)
         ctx.grad_out = grad_out
         return h
@@ -337,6 +343,29 @@ class _FoldedSideBySide(torch.autograd.Function):
         torch.mul(d.view(c, n_layers, c).permute(1, 0, 2),
                   scale_cat.view(n_layers, 1, c), out=out)
         return out, None, None
+
+
+class _FoldedWeights(torch.autograd.Function):
+    """Both folded weight sets of all GCNII layers from the stack ``[W1_0.., W2_0..]`` in one
+    launch forward and one backward (ops.gcn2_fold_weights)."""
+
+    @staticmethod
+    def forward(ctx, ws, alpha, betas):
+        ctx.alpha, ctx.betas = alpha, betas
+        ctx.set_materialize_grads(False)
+        return ops.gcn2_fold_weights(ws, alpha, betas)
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        n_layers = len(ctx.betas)
+        if d1 is None and d2 is None:
+            return None, None, None
+        if d1 is None:
+            d1 = torch.zeros((n_layers, d2.size(0), d2.size(0)), dtype=d2.dtype, device=d2.device)
+        if d2 is None:
+            d2 = torch.zeros((d1.size(1), n_layers * d1.size(1)), dtype=d1.dtype, device=d1.device)
+        return ops.gcn2_fold_weights_backward(d1.contiguous(), d2.contiguous(), ctx.alpha,
+                                              ctx.betas), None, None
 
 
 class _X0Terms(torch.autograd.Function):
@@ -539,6 +568,10 @@ def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
     n_layers, c = len(convs), convs[0].channels
     dev, dt = x_0.device, x_0.dtype
     alpha = convs[0].alpha
+    if x_0.is_cuda and dt == torch.float32 and n_layers <= 64:
+        ws = torch.stack([conv.weight1 for conv in convs] + [conv.weight2 for conv in convs])
+        w1f, w2cat = _FoldedWeights.apply(ws, alpha, tuple(conv.beta for conv in convs))
+        return _batched_terms(x_0, w1f, w2cat, n_layers, grad_stack)
     consts = convs[0].__dict__.setdefault("_batched_consts", {})
     key = (dev, dt, n_layers, alpha)
     if key not in consts:   # built once: no host-to-device copy inside a step
@@ -553,6 +586,11 @@ def gcn2_batched_terms(convs, x_0: Tensor, grad_stack: Optional[Tensor] = None):
     c1, b1, c2cat, b2cat = consts[key]
     w1f = torch.addcmul(c1, torch.stack([conv.weight1 for conv in convs]), b1)
     w2cat = _FoldedSideBySide.apply(torch.stack([conv.weight2 for conv in convs]), c2cat, b2cat)
+    return _batched_terms(x_0, w1f, w2cat, n_layers, grad_stack)
+
+
+def _batched_terms(x_0: Tensor, w1f: Tensor, w2cat: Tensor, n_layers: int,
+                   grad_stack: Optional[Tensor]):
     terms = _X0Terms.apply(x_0, w2cat, n_layers, grad_stack)
     if not (torch.is_grad_enabled() and w1f.requires_grad):
         return w1f.unbind(0), terms, None

@@ -419,6 +419,75 @@ def tn_finish_batched(parts, tails, out: Tensor) -> Tensor:
     return out
 
 
+def relu_rows_(x: Tensor) -> Tensor:
+    """``x.relu_()`` over a [rows, width] matrix at streaming rate (incagg_relu_rows_f32).
+    Outside autograd."""
+    _need_cuda(x, "x")
+    _rows_f32(x, "x")
+    with _on_device(x.device):
+        check(lib().incagg_relu_rows_f32(_ptr(x), _ld(x), x.size(0), x.size(1),
+                                         _stream_of(x.device)))
+    return x
+
+
+def gate_add_rows_(dst: Tensor, src: Tensor, gate: Tensor) -> Tensor:
+    """``dst += where(gate > 0, src, 0)`` in one launch (incagg_gate_add_rows_f32)."""
+    _need_cuda(dst, "dst")
+    for t, name in ((dst, "dst"), (src, "src"), (gate, "gate")):
+        _rows_f32(t, name, dst.device)
+    if src.shape != dst.shape or gate.shape != dst.shape:
+        raise ValueError("dst, src and gate must have one shape")
+    with _on_device(dst.device):
+        check(lib().incagg_gate_add_rows_f32(_ptr(dst), _ld(dst), _ptr(src), _ld(src), _ptr(gate),
+                                             _ld(gate), dst.size(0), dst.size(1),
+                                             _stream_of(dst.device)))
+    return dst
+
+
+def _fold_check(n_layers: int, c: int, betas) -> "ctypes.Array":
+    if len(betas) != n_layers:
+        raise ValueError("one beta per layer")
+    return (ctypes.c_float * n_layers)(*[float(b) for b in betas])
+
+
+def gcn2_fold_weights(ws: Tensor, alpha: float, betas) -> Tuple[Tensor, Tensor]:
+    """GCNII's folded weights of all layers in one launch (incagg_gcn2_fold_weights_f32):
+    ``ws`` = ``[W1_0 .. W1_{L-1}, W2_0 .. W2_{L-1}]`` ([2L, C, C]) ->
+    ``w1f[l] = (1-alpha)(beta_l W1_l + (1-beta_l) I)`` ([L, C, C]) and ``w2cat`` ([C, L*C]) whose
+    column block l is ``alpha (beta_l W2_l + (1-beta_l) I)``."""
+    _need_cuda(ws, "ws")
+    if ws.dim() != 3 or ws.size(0) % 2 or ws.size(1) != ws.size(2) or ws.dtype != torch.float32 \
+            or not ws.is_contiguous():
+        raise ValueError("ws must be a contiguous [2L, C, C] float32 tensor")
+    n_layers, c = ws.size(0) // 2, ws.size(1)
+    beta = _fold_check(n_layers, c, betas)
+    w1f = torch.empty((n_layers, c, c), dtype=torch.float32, device=ws.device)
+    w2cat = torch.empty((c, n_layers * c), dtype=torch.float32, device=ws.device)
+    with _on_device(ws.device):
+        check(lib().incagg_gcn2_fold_weights_f32(_ptr(ws), n_layers, c, float(alpha),
+                                                 ctypes.addressof(beta), _ptr(w1f), _ptr(w2cat),
+                                                 _stream_of(ws.device)))
+    return w1f, w2cat
+
+
+def gcn2_fold_weights_backward(dw1f: Tensor, dw2cat: Tensor, alpha: float, betas) -> Tensor:
+    """Gradient of ``ws`` from the gradients of :func:`gcn2_fold_weights`' results."""
+    _need_cuda(dw1f, "dw1f")
+    n_layers, c = dw1f.size(0), dw1f.size(1)
+    if dw1f.shape != (n_layers, c, c) or dw2cat.shape != (c, n_layers * c) \
+            or dw1f.dtype != torch.float32 or dw2cat.dtype != torch.float32 \
+            or not dw1f.is_contiguous() or not dw2cat.is_contiguous() \
+            or dw2cat.device != dw1f.device:
+        raise ValueError("gradients must be contiguous float32 [L, C, C] and [C, L*C]")
+    beta = _fold_check(n_layers, c, betas)
+    dws = torch.empty((2 * n_layers, c, c), dtype=torch.float32, device=dw1f.device)
+    with _on_device(dw1f.device):
+        check(lib().incagg_gcn2_fold_weights_backward_f32(
+            _ptr(dw1f), _ptr(dw2cat), n_layers, c, float(alpha), ctypes.addressof(beta),
+            _ptr(dws), _stream_of(dw1f.device)))
+    return dws
+
+
 def column_sums(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """``x.sum(0)`` of a tall ``[rows, width]`` matrix (incagg_column_sums_f32): bias gradients.
     Two launches, fixed summation order."""

@@ -298,6 +298,28 @@ typedef struct incagg_adam_segment {
 int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void *stream);
 
+/* x = max(x, 0) in place over [rows, width] (pitch ld): the activation in front of a model's
+ * classifier (models/gcn2.py:136), at streaming rate. */
+int incagg_relu_rows_f32(float *x, int64_t ld, int64_t rows, int64_t width, void *stream);
+/* dst[i, c] += src[i, c] wherever gate[i, c] > 0: a relu's backward added onto a gradient that
+ * exists already (the x_0 branch of GCNII joining the first layer's gradient), one launch. */
+int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds,
+                             const float *gate, int64_t ldg, int64_t rows, int64_t width,
+                             void *stream);
+
+/* GCNII layers with separate weights (PyG's GCN2Conv as called at models/gcn2.py:46-48):
+ *   out_l = (1 - alpha) (A x) ((1 - beta_l) I + beta_l W1_l) + alpha x_0 ((1 - beta_l) I + beta_l W2_l)
+ * The identity parts folded into the weights of all L layers (<= 64) by one launch:
+ *   w1f[l] = (1 - alpha)(beta_l W1_l + (1 - beta_l) I)               device fp32 [L, C, C]
+ *   w2cat[:, l C:(l+1) C] = alpha (beta_l W2_l + (1 - beta_l) I)      device fp32 [C, L C]
+ * ws: device fp32 [2 L, C, C] = W1_0 .. W1_{L-1}, W2_0 .. W2_{L-1}; beta: HOST float[L].
+ * The backward call maps gradients of w1f / w2cat onto a gradient of ws (same layout). */
+int incagg_gcn2_fold_weights_f32(const float *ws, int64_t n_layers, int64_t c, float alpha,
+                                 const float *beta, float *w1f, float *w2cat, void *stream);
+int incagg_gcn2_fold_weights_backward_f32(const float *dw1f, const float *dw2cat, int64_t n_layers,
+                                          int64_t c, float alpha, const float *beta, float *dws,
+                                          void *stream);
+
 /* ------------------------------------------------------------------ History rows
  * out[k,:] = emb[n_id[k],:]            (History.pull, history.py:33-39; the
  * gathered half of read_async, csrc/cuda/async_cuda.cu:95-110).

@@ -145,3 +145,46 @@ def test_adam_counts_steps_inside_a_replayed_graph(dev):
         ref.step()
     for a, b in zip(ours, theirs):
         assert float((a - b).abs().max()) <= 2e-6 + 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("rows,width,pitch", [(16326, 256, 288), (1000, 47, 48), (7, 5, 5)])
+def test_relu_and_gate_add_rows(ops, dev, rows, width, pitch):
+    g = torch.Generator(device=dev).manual_seed(rows)
+    base = torch.randn(rows, pitch, device=dev, generator=g)
+    x = base[:, :width]
+    want = x.clamp(min=0)
+    keep = base[:, width:].clone()
+    assert torch.equal(ops.relu_rows_(x), want)
+    assert torch.equal(base[:, width:], keep)              # padding untouched
+    dst = torch.randn(rows, pitch, device=dev, generator=g)[:, :width]
+    src = torch.randn(rows, width, device=dev, generator=g)
+    gate = torch.randn(rows, pitch, device=dev, generator=g)[:, :width]
+    want = dst + torch.where(gate > 0, src, torch.zeros_like(src))
+    assert torch.equal(ops.gate_add_rows_(dst, src, gate), want)
+    with pytest.raises(ValueError):
+        ops.gate_add_rows_(dst, src[:-1], gate)
+
+
+@pytest.mark.parametrize("n_layers,c", [(8, 256), (3, 20), (1, 7)])
+def test_gcn2_weight_fold_matches_the_formulas(ops, dev, n_layers, c):
+    """Folded GCNII weights of all layers and their gradient against plain torch."""
+    import math
+    from torch_geometric_autoscale.nn import _FoldedWeights
+    g = torch.Generator(device=dev).manual_seed(c)
+    alpha = 0.1
+    betas = tuple(math.log(0.5 / (l + 1) + 1) for l in range(n_layers))
+    ws = torch.randn(2 * n_layers, c, c, device=dev, generator=g, requires_grad=True)
+    w1f, w2cat = _FoldedWeights.apply(ws, alpha, betas)
+    eye = torch.eye(c, device=dev)
+    ref = ws.detach().clone().requires_grad_()
+    r1 = torch.stack([(1 - alpha) * (b * ref[l] + (1 - b) * eye) for l, b in enumerate(betas)])
+    r2 = torch.cat([alpha * (b * ref[n_layers + l] + (1 - b) * eye) for l, b in enumerate(betas)], 1)
+    assert torch.allclose(w1f, r1, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(w2cat, r2, rtol=1e-6, atol=1e-7)
+    d1 = torch.randn(w1f.shape, device=dev, generator=g)
+    d2 = torch.randn(w2cat.shape, device=dev, generator=g)
+    torch.autograd.backward([w1f, w2cat], [d1, d2])
+    torch.autograd.backward([r1, r2], [d1, d2])
+    assert torch.allclose(ws.grad, ref.grad, rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        ops.gcn2_fold_weights(ws.detach(), alpha, betas[:-1] if n_layers > 1 else betas + (0.5,))
