@@ -725,18 +725,21 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void zero_rows_kernel(
   for (int c = lane; c < width; c += kWave) y[(size_t)row * ldy + c] = 0.f;
 }
 
+// d = f(a) - b row by row; f = max(0, .) when relu_a (kernel argument: a scalar branch), else
+// the identity.
 template <int VEC>
 __global__ __launch_bounds__(256) void rows_sub_kernel(const float *a, long long lda,
                                                       const float *b, long long ldb,
-                                                      long long n_rows, int width, float *d,
-                                                      long long ldd) {
+                                                      long long n_rows, int width, int relu_a,
+                                                      float *d, long long ldd) {
   const int per_row = width / VEC;
   const long long total = n_rows * per_row;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / per_row;
     const int c = (int)(i - r * per_row) * VEC;
-    stv<VEC>(d + r * ldd + c, ldv<VEC>(a + r * lda + c) - ldv<VEC>(b + r * ldb + c));
+    stv<VEC>(d + r * ldd + c,
+             vrelu<VEC>(ldv<VEC>(a + r * lda + c), relu_a != 0) - ldv<VEC>(b + r * ldb + c));
   }
 }
 
@@ -1012,6 +1015,12 @@ extern "C" int incagg_set_tuning(const char *key, int value) {
 extern "C" int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, int64_t ldb,
                                    int64_t n_rows, int64_t width, float *d, int64_t ldd,
                                    void *stream) {
+  return incagg_rows_sub_relu_f32(a, lda, b, ldb, n_rows, width, 0, d, ldd, stream);
+}
+
+extern "C" int incagg_rows_sub_relu_f32(const float *a, int64_t lda, const float *b, int64_t ldb,
+                                        int64_t n_rows, int64_t width, int relu_a, float *d,
+                                        int64_t ldd, void *stream) {
   INCAGG_REQUIRE(n_rows >= 0 && width >= 0 && width < INT_MAX, "bad size");
   if (n_rows == 0 || width == 0) return INCAGG_OK;
   INCAGG_REQUIRE(a && b && d, "null pointer");
@@ -1022,10 +1031,10 @@ extern "C" int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (vec4)
     hipLaunchKernelGGL((rows_sub_kernel<4>), dim3(blocks), dim3(256), 0, s, a, lda, b, ldb, n_rows,
-                       (int)width, d, ldd);
+                       (int)width, relu_a, d, ldd);
   else
     hipLaunchKernelGGL((rows_sub_kernel<1>), dim3(blocks), dim3(256), 0, s, a, lda, b, ldb, n_rows,
-                       (int)width, d, ldd);
+                       (int)width, relu_a, d, ldd);
   INCAGG_HIP_TRY(hipGetLastError());
   return INCAGG_OK;
 }

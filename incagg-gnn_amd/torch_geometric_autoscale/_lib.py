@@ -36,6 +36,7 @@ SIGNATURES = {
                                               _vp, _vp]),
     "incagg_set_tuning": (_int, [_c.c_char_p, _int]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "incagg_rows_sub_relu_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp]),
     "incagg_tn_finish_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_tn_finish_batched_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "incagg_relu_rows_f32": (_int, [_vp, _i64, _i64, _i64, _vp]),

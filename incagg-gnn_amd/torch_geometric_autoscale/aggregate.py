@@ -169,9 +169,17 @@ def spmm(adj: SparseTensor, x: Tensor, reduce: str = "sum", scale: float = 1.0,
 
 def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,
                      reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
-                     add_scale: float = 0.0, fused: bool = True) -> Tensor:
-    """``adj @ (x - m_in) + m_ag`` in one launch; ``m_in`` / ``m_ag`` are constants
-    (the reference detaches both, models/gcn2.py:246-247)."""
+                     add_scale: float = 0.0, fused: bool = True, relu_x: bool = False,
+                     gate_grad: bool = False, grad_out: Optional[Tensor] = None) -> Tensor:
+    """``adj @ (x - m_in) + m_ag``; ``m_in`` / ``m_ag`` are constants (the reference detaches
+    both, models/gcn2.py:246-247).  ``fused``: one launch gathering both operands; otherwise a
+    streaming subtract and the plain aggregation with ``m_ag`` riding in its epilogue (gathers
+    touch one operand instead of two).
+
+    ``relu_x`` / ``gate_grad`` / ``grad_out`` as in :func:`spmm` (two-pass form only): ``x``
+    holds pre-activations and ``relu(x) - m_in`` is aggregated / ``x`` is the output of a relu
+    whose backward this call's backward takes over / where the backward pass leaves the gradient
+    w.r.t. ``x``."""
     if adj.size(0) != adj.size(1):
         raise ValueError("the incremental aggregate needs the square in-batch adjacency")
     x = _as_rows(x)
@@ -183,25 +191,42 @@ def incagg_aggregate(adj: SparseTensor, x: Tensor, m_in: Tensor, m_ag: Tensor,
         add = _as_rows(add)
     red = "mean" if reduce == "mean" else "sum"
     if fused:
+        if relu_x or gate_grad or grad_out is not None:
+            raise ValueError("relu_x / gate_grad / grad_out need the two-pass form (fused=False)")
         return _IncAgg.apply(x, add, m_in, m_ag, adj, red, float(scale), float(add_scale))
-    # two-pass form: one streaming subtract, then the plain aggregation with M_ag (and the
-    # caller's add term) riding in its epilogue; gathers touch one operand instead of two.
-    d = _RowsSub.apply(x[:b], m_in)
-    w = x.size(1)
-    m_ag = m_ag[:b, :w]
+    fuse = (bool(relu_x), bool(gate_grad), grad_out)
     if add is None:
-        return _SpMM.apply(d, None, m_ag, adj, red, float(scale), float(scale), None)
-    h = _SpMM.apply(d, None, m_ag, adj, red, 1.0, 1.0, None)
+        return _IncAggRows.apply(x, m_in, m_ag, adj, red, float(scale), *fuse)
+    h = _IncAggRows.apply(x, m_in, m_ag, adj, red, 1.0, *fuse)
     if scale != 1.0:
         h = h * scale
     return h + add_scale * add[:b]
 
 
-class _RowsSub(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, a, b):
-        return ops.rows_sub(_as_rows(a), b)
+class _IncAggRows(torch.autograd.Function):
+    """``scale * (reduce(A_ib, f(x) - M_in) + M_ag)`` as a streaming subtract (ops.rows_sub)
+    followed by the plain aggregation with ``M_ag`` in its epilogue; ``f`` = relu with
+    ``relu_x``.  Backward: the transposed aggregation, its result zeroed where ``x <= 0`` when
+    the relu is this call's (``relu_x``) or the caller's to be folded in (``gate_grad``)."""
 
     @staticmethod
-    def backward(ctx, g):
-        return g, None
+    def forward(ctx, x, m_in, m_ag, adj, reduce, scale, relu_x, gate_grad, grad_out):
+        b, w = adj.size(0), x.size(1)
+        d = ops.rows_sub(x if x.size(0) == b else x[:b], m_in, relu_a=relu_x)
+        rowptr, col, val = adj.device_csr()
+        h = ops.spmm_csr(rowptr, col, val, d, adj.size(1), reduce, scale, m_ag[:b, :w], scale,
+                         plan=adj.plan_edges())
+        ctx.gated = relu_x or gate_grad
+        if ctx.gated:
+            ctx.save_for_backward(x)
+        ctx.adj, ctx.reduce, ctx.scale, ctx.x_rows, ctx.grad_out = adj, reduce, scale, x.size(0), grad_out
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 9
+        gate = ctx.saved_tensors[0] if ctx.gated else None
+        dx = _transposed_aggregate(ctx.adj, _as_rows(dy), ctx.reduce, ctx.scale, 0, ctx.adj.size(1),
+                                   ctx.x_rows, gate, ctx.grad_out)
+        return (dx,) + (None,) * 8

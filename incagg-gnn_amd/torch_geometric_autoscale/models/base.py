@@ -429,8 +429,16 @@ class ScalableGNN(torch.nn.Module):
             m_ag = self.pool_ag.synchronize_pull()[:batch_size, :width]
             return m_in, m_ag
         if offset is not None and count is not None:
-            m_in = self.histories[layer].pull_chunks(self._local(offset), count)
-            m_ag = self.histories_ag[layer].pull_chunks(self._local(offset), count)
+            t_in, t_ag = self.histories[layer], self.histories_ag[layer]
+            if (count.numel() == 1 and t_in.emb.is_cuda and t_ag.emb.is_cuda
+                    and _same_device(t_in.emb.device, self.device)
+                    and _same_device(t_ag.emb.device, self.device)):
+                # one range of rows of tables that live where the model computes: read where
+                # they are (nothing writes the tables during an incremental-aggregation step)
+                lo = int(self._local(offset)[0])
+                return (t_in.emb[lo:lo + batch_size, :width], t_ag.emb[lo:lo + batch_size, :width])
+            m_in = t_in.pull_chunks(self._local(offset), count)
+            m_ag = t_ag.pull_chunks(self._local(offset), count)
         elif self.partition_ctx is not None:
             raise RuntimeError("partition-parallel batches address their rows by (offset, count)")
         else:
@@ -527,20 +535,35 @@ class ScalableGNN(torch.nn.Module):
         batch_size, n_id, offset, count = (tuple(args) + (None,) * 4)[:4]
         b = batch_size
         state: Dict[str, Any] = {}
-        x = self._embed(x, state, b)[:b]
+        # Activations between two layers applied where they are consumed, as in :meth:`forward`
+        # (two-pass form of the incremental aggregate only): `x` then holds pre-activations,
+        # the subtraction reads max(0, x), and the aggregation's backward returns the gradient
+        # w.r.t. the pre-activations.
+        state['defer_relu'] = bool(b is not None and not self.fused_incagg
+                                   and self._defers_relu())
+        x = self._embed(x, state, b)
+        x = x if x.size(0) == b else x[:b]
         adj = self._adj(adj_t)
+        relu_pending = False
         for i in range(self.num_layers):
             x = self._layer_input(i, x)
             m_in, m_ag = self._pull_batch_rows(i, b, n_id, offset, count, x.size(1))
             mix = self._mix(i, state, b)
+            fuse = {}
+            if state['defer_relu']:
+                fuse = dict(relu_x=relu_pending,
+                            gate_grad=i == 0 and state.get('embed_grad_gated', False))
+                if relu_pending and 'grad_blocks' in state:
+                    fuse['grad_out'] = state['grad_blocks'][i - 1]
             if mix is None:
                 agg = incagg_aggregate(adj, x, m_in, m_ag, reduce=self.agg_reduce,
-                                       fused=self.fused_incagg)
+                                       fused=self.fused_incagg, **fuse)
                 x = self._update(i, agg, x, state)
             else:
                 mixed = incagg_aggregate(adj, x, m_in, m_ag, self.agg_reduce, *mix,
-                                         fused=self.fused_incagg)
+                                         fused=self.fused_incagg, **fuse)
                 x = self._update_mixed(i, mixed, x, state)
+            relu_pending = state.pop('relu_deferred', False)
             self._free_batch_rows()
         return x, 0.0, 0, 0
 

@@ -331,17 +331,20 @@ def spmm_csr_incagg(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: T
     return out
 
 
-def rows_sub(a: Tensor, b: Tensor) -> Tensor:
+def rows_sub(a: Tensor, b: Tensor, relu_a: bool = False) -> Tensor:
+    """``a - b[:rows, :width]`` (``max(0, a) - b`` with ``relu_a``), written with the row pitch
+    the aggregation wants for a matrix it gathers from (incagg_rows_sub_relu_f32)."""
     _need_cuda(a, "a")
     _rows_f32(a, "a")
     _rows_f32(b, "b", a.device)
     n, w = a.size(0), a.size(1)
     if b.size(0) < n or b.size(1) < w:
         raise ValueError("b is smaller than a")
-    out = torch.empty((n, w), dtype=torch.float32, device=a.device)
+    out = rows_empty(n, w, a.device)
     with _on_device(a.device):
-        check(lib().incagg_rows_sub_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), n, w, _ptr(out), _ld(out),
-                                        _stream_of(a.device)))
+        check(lib().incagg_rows_sub_relu_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), n, w,
+                                             1 if relu_a else 0, _ptr(out), _ld(out),
+                                             _stream_of(a.device)))
     return out
 
 

@@ -232,6 +232,12 @@ int incagg_set_tuning(const char *key, int value);
 int incagg_rows_sub_f32(const float *a, int64_t lda, const float *b, int64_t ldb,
                         int64_t n_rows, int64_t width, float *d, int64_t ldd,
                         void *stream);
+/* d[i,:] = max(0, a[i,:]) - b[i,:] when relu_a, else as incagg_rows_sub_f32: `a` then holds the
+ * pre-activations of the layer below, whose relu (models/gcn2.py:131-135) is applied where the
+ * incremental aggregate reads its input instead of in a pass of its own. */
+int incagg_rows_sub_relu_f32(const float *a, int64_t lda, const float *b, int64_t ldb,
+                             int64_t n_rows, int64_t width, int relu_a, float *d, int64_t ldd,
+                             void *stream);
 
 /* out[i, j] = sum_s parts[s, i, j] + sum_r a_tail[r, i] * b_tail[r, j]   (parts: S contiguous
  * [m, n] matrices; a_tail [R, m] ld = lda, b_tail [R, n] ld = ldb; out [m, n] ld = ldo).

@@ -73,8 +73,8 @@ def _spmm_csr_incagg(rowptr32, col32, val, x, m_in, m_ag, reduce="sum", scale=1.
     return h
 
 
-def _rows_sub(a, b):
-    return a - b[:a.size(0), :a.size(1)]
+def _rows_sub(a, b, relu_a=False):
+    return (torch.relu(a) if relu_a else a) - b[:a.size(0), :a.size(1)]
 
 
 def _gather_rows(emb, n_id, out=None, device=None):

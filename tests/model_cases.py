@@ -210,3 +210,53 @@ def check_training_step(name, model, data, ptr, device, vr):
     assert any(float(g.abs().sum()) > 0 for g in grads)
     opt.step()
     return float(loss.detach())
+
+
+def check_deferred_activation(device, vr):
+    """GCNII leaves the relu between two layers to its consumers (the next aggregation -- or the
+    subtraction in front of the incremental aggregate -- reads max(0, x), the History push stores
+    max(0, x), the aggregation's backward returns the gradient w.r.t. the pre-activations, the
+    first aggregation's backward also masks the embedding's gradient): outputs, table contents
+    and every weight gradient must equal the plain formulation's (models/gcn2.py:131-135 for the
+    push/pull step, models/gcn2.py:246-262 for the incremental one)."""
+    from torch_geometric_autoscale.loader import partition_batch
+    from torch_geometric_autoscale.models import GCN2
+    data, ptr = make_graph()
+    device = torch.device(device)
+    results = {}
+    for shared in (False, True):
+        for defer in (True, False):
+            torch.manual_seed(3)
+            model = GCN2(data.num_nodes, data.x.size(1), 32, 5, 4, alpha=0.1, theta=0.5,
+                         shared_weights=shared, dropout=0.0, device=device).to(device)
+            gen = torch.Generator().manual_seed(4)
+            for h in list(model.histories) + list(model.histories_ag):
+                h.emb.copy_(torch.randn(h.emb.shape, generator=gen))
+            if not defer:
+                model._defers_relu = lambda: False
+            assert model._defers_relu() == defer
+            model.train()
+            # (one partition: its table rows are read in place by the incremental step on the
+            # GPU; two: they are copied out chunk by chunk)
+            for parts in ([1, 4], [2]):
+                sub = partition_batch(data, ptr, parts, in_batch_only=vr)
+                b = sub.batch_size
+                call = model.VR_call if vr else model
+                model.zero_grad(set_to_none=True)
+                out = call(sub.data.x.to(device), sub.data.adj_t.to(device), b, sub.n_id, sub.offset,
+                           sub.count)["out"]
+                torch.nn.functional.cross_entropy(out, sub.data.y[:b].to(device)).backward()
+                results[(shared, defer, len(parts))] = (
+                    out.detach().cpu().clone(), [h.emb.cpu().clone() for h in model.histories],
+                    {k: p.grad.cpu().clone() for k, p in model.named_parameters()
+                     if p.grad is not None})
+    for key, (o1, t1, g1) in results.items():
+        if not key[1]:
+            continue
+        o2, t2, g2 = results[(key[0], False, key[2])]
+        assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-6), key
+        for a, b_ in zip(t1, t2):
+            assert torch.equal(a, b_), key
+        assert g1.keys() == g2.keys() and len(g1) >= 6
+        for k in g1:
+            assert torch.allclose(g1[k], g2[k], rtol=1e-4, atol=1e-6), (key, k)

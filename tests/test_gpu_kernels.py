@@ -418,6 +418,9 @@ def test_incagg_matches_oracle(ops, dev, width, reduce, variant):
     # the two-pass form agrees
     d = ops.rows_sub(args[3], args[4])
     assert torch.equal(d.cpu(), torch.from_numpy(x - mi))
+    # ... also with the relu of the layer below applied to the first operand as it is read
+    d = ops.rows_sub(args[3], args[4], relu_a=True)
+    assert torch.equal(d.cpu(), torch.from_numpy(np.maximum(x, 0) - mi))
 
 
 @pytest.mark.parametrize("width", [256, 41, 100, 1024, 6])

@@ -223,42 +223,11 @@ def test_batched_gcn2_terms_and_fused_embed_have_the_plain_gradients():
         assert torch.allclose(a, b_, rtol=1e-10, atol=1e-10)
 
 
-def test_deferred_activation_gives_the_same_outputs_and_gradients():
-    """GCNII leaves the relu between two layers to its consumers (the next aggregation reads
-    max(0, x), the History push stores max(0, x), the aggregation's backward returns the
-    gradient w.r.t. the pre-activations, the first aggregation's backward also masks the
-    embedding's gradient): outputs, table contents and every weight gradient must equal the
-    plain formulation's (models/gcn2.py:131-135)."""
+@pytest.mark.parametrize("vr", [False, True])
+def test_deferred_activation_gives_the_same_outputs_and_gradients(vr):
+    """Host orchestration of model_cases.check_deferred_activation (kernels swapped for the
+    oracle); the GPU run of the same check is in test_gpu_models.py."""
     import model_cases as mc
     from cpu_shim import cpu_kernels
-    from torch_geometric_autoscale.loader import partition_batch
-    from torch_geometric_autoscale.models import GCN2
-    data, ptr = mc.make_graph()
-    results = {}
     with cpu_kernels():
-        for shared in (False, True):
-            for defer in (True, False):
-                torch.manual_seed(3)
-                model = GCN2(data.num_nodes, data.x.size(1), 32, 5, 4, alpha=0.1, theta=0.5,
-                             shared_weights=shared, dropout=0.0, device="cpu")
-                for h in model.histories:
-                    h.emb.copy_(torch.randn(h.emb.shape, generator=torch.Generator().manual_seed(4)))
-                if not defer:
-                    model._defers_relu = lambda: False
-                assert model._defers_relu() == defer
-                model.train()
-                sub = partition_batch(data, ptr, [1, 4])
-                b = sub.batch_size
-                out = model(sub.data.x, sub.data.adj_t, b, sub.n_id, sub.offset, sub.count)["out"]
-                torch.nn.functional.cross_entropy(out, sub.data.y[:b]).backward()
-                results[(shared, defer)] = (
-                    out.detach().clone(), [h.emb.clone() for h in model.histories],
-                    {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
-    for shared in (False, True):
-        (o1, t1, g1), (o2, t2, g2) = results[(shared, True)], results[(shared, False)]
-        assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-6)
-        for a, b_ in zip(t1, t2):
-            assert torch.equal(a, b_)
-        assert g1.keys() == g2.keys() and len(g1) >= 6
-        for k in g1:
-            assert torch.allclose(g1[k], g2[k], rtol=1e-4, atol=1e-6), k
+        mc.check_deferred_activation("cpu", vr)
