@@ -430,13 +430,18 @@ class ScalableGNN(torch.nn.Module):
             return m_in, m_ag
         if offset is not None and count is not None:
             t_in, t_ag = self.histories[layer], self.histories_ag[layer]
-            if (count.numel() == 1 and t_in.emb.is_cuda and t_ag.emb.is_cuda
+            if (t_in.emb.is_cuda and t_ag.emb.is_cuda
                     and _same_device(t_in.emb.device, self.device)
                     and _same_device(t_ag.emb.device, self.device)):
-                # one range of rows of tables that live where the model computes: read where
-                # they are (nothing writes the tables during an incremental-aggregation step)
-                lo = int(self._local(offset)[0])
-                return (t_in.emb[lo:lo + batch_size, :width], t_ag.emb[lo:lo + batch_size, :width])
+                # one range of rows (partitions that are neighbours in the table form one) of
+                # tables that live where the model computes: read where they are (nothing
+                # writes the tables during an incremental-aggregation step)
+                lo, rows = ops.merge_row_chunks(self._local(offset), count)
+                if lo.numel() == 1 and int(rows[0]) == batch_size:
+                    lo = int(lo[0])
+                    if 0 <= lo and lo + batch_size <= min(t_in.emb.size(0), t_ag.emb.size(0)):
+                        return (t_in.emb[lo:lo + batch_size, :width],
+                                t_ag.emb[lo:lo + batch_size, :width])
             m_in = t_in.pull_chunks(self._local(offset), count)
             m_ag = t_ag.pull_chunks(self._local(offset), count)
         elif self.partition_ctx is not None:
@@ -664,7 +669,8 @@ class ScalableGNN(torch.nn.Module):
             return _ids_on(data.adj_t, n_id, self.device)
 
         def run_layer(i, x, adj_t, batch_size, offset, count, state, halo=None, halo_ids=None):
-            offset = self._local(offset)
+            # (partitions that are neighbours in the table count as one range)
+            offset, count = ops.merge_row_chunks(self._local(offset), count)
             # a batch that is ONE range of table rows: the aggregation writes its result where
             # the table of aggregates keeps it (no push of its own)
             dest = None
@@ -732,14 +738,14 @@ class ScalableGNN(torch.nn.Module):
                     # in-batch rows by chunks (the update needs them); out-of-batch rows are
                     # read from the table by the aggregation itself
                     hist = self.histories[i]
-                    loc = self._local(offset)
-                    if count.numel() == 1:      # one contiguous range: the table rows themselves
+                    loc, cnt = ops.merge_row_chunks(self._local(offset), count)
+                    if cnt.numel() == 1:        # one contiguous range: the table rows themselves
                         o = int(loc[0])
                         x = hist.emb[o:o + batch_size]
                     else:
                         x = torch.empty((batch_size, hist.embedding_dim), dtype=hist.emb.dtype,
                                         device=self.device)
-                        ops.copy_row_chunks(x, hist.emb, loc, count, packed_is_src=False,
+                        ops.copy_row_chunks(x, hist.emb, loc, cnt, packed_is_src=False,
                                             device=self.device)
                     if plan is None:
                         halo = hist.emb

@@ -5,7 +5,7 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import BatchNorm1d, ModuleList
 
-from ..nn import GCNConv, RowsLinear
+from ..nn import GCNConv, RowsLinear, relu_into
 from .base import ScalableGNN
 
 
@@ -91,7 +91,7 @@ class GCN(ScalableGNN):
                 h = self.bns[layer](h)
             if self.residual and h.size(-1) == x.size(-1):
                 h = h + (x if x.size(0) == h.size(0) else x[:h.size(0)])
-            h = h.relu_()
+            h = relu_into(h)
         if layer == self.num_layers - 1 and self.linear:
             h = F.dropout(h, p=self.dropout, training=self.training)
             h = self.lins[1](h)

@@ -308,13 +308,20 @@ class _ReluInPlace(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         h, = ctx.saved_tensors
+        if ctx.grad_out is None:
+            return torch.ops.aten.threshold_backward(g, h, 0), None
         return torch.ops.aten.threshold_backward.grad_input(g, h, 0, grad_input=ctx.grad_out), None
 
 
-def relu_into(h: Tensor, grad_out: Optional[Tensor]) -> Tensor:
-    """In-place relu; ``grad_out``: where its backward should leave the gradient of ``h``."""
-    if grad_out is None or not (torch.is_grad_enabled() and h.requires_grad) \
-            or grad_out.shape != h.shape:
+def relu_into(h: Tensor, grad_out: Optional[Tensor] = None) -> Tensor:
+    """In-place relu (the row kernel for fp32 matrices on the GPU, also with padded row
+    pitches); ``grad_out``: where its backward should leave the gradient of ``h``."""
+    rows_kernel = h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.stride(1) == 1
+    if not (torch.is_grad_enabled() and h.requires_grad):
+        return ops.relu_rows_(h) if rows_kernel else h.relu_()
+    if grad_out is not None and grad_out.shape != h.shape:
+        grad_out = None
+    if grad_out is None and not rows_kernel:
         return h.relu_()
     return _ReluInPlace.apply(h, grad_out)
 
@@ -453,8 +460,11 @@ class GCNConv(torch.nn.Module):
 
     def update(self, agg: Tensor) -> Tensor:
         """Dense part applied to an aggregate of the layer INPUT (models/gcn.py:242-244)."""
-        h = self.lin(agg)
-        return h if self.bias is None else h + self.bias
+        if self.bias is None or agg.dim() != 2 or not agg.is_cuda:
+            h = self.lin(agg)
+            return h if self.bias is None else h + self.bias
+        # bias in the GEMM's epilogue, its gradient as streaming column sums
+        return _RowsLinear.apply(agg, self.lin.weight, self.bias, True)
 
     def forward(self, x: Tensor, adj_t: SparseTensor) -> Tensor:
         if self.in_channels <= self.out_channels:

@@ -10,6 +10,7 @@ import collections
 import ctypes
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -532,11 +533,18 @@ class _SoftmaxXent(torch.autograd.Function):
         logits, labels, ws = ctx.saved_tensors
         rows, classes = logits.shape
         dloss = dloss.contiguous()
-        dlogits = torch.empty((rows, classes), dtype=torch.float32, device=logits.device)
+        # laid out like the logits: where those are rows of a wider allocation (the padded,
+        # 16-byte-aligned row pitch of an aggregation's output), so is their gradient -- it is
+        # the input of that aggregation's backward launch, which takes the feature-sliced kernel
+        # only for aligned rows
+        pitch = logits.stride(0) if rows > 1 and logits.stride(0) >= classes else classes
+        dlogits = torch.empty((rows, pitch), dtype=torch.float32, device=logits.device)
+        if pitch != classes:
+            dlogits = dlogits[:, :classes]
         with _on_device(logits.device):
             check(lib().incagg_softmax_xent_backward_f32(
                 _ptr(logits), _ld(logits), _ptr(labels), rows, classes, _ptr(ws), _ptr(dloss),
-                _ptr(dlogits), classes, _stream_of(logits.device)))
+                _ptr(dlogits), pitch, _stream_of(logits.device)))
         return dlogits, None
 
 
@@ -612,10 +620,31 @@ def _host_i64(t: Tensor, name: str) -> Tensor:
     return t.to(torch.int64).contiguous()
 
 
+def merge_row_chunks(offset: Tensor, count: Tensor) -> Tuple[Tensor, Tensor]:
+    """The same rows in the same order as the chunks ``(offset[i], count[i])`` describe, in as
+    few chunks as possible: a chunk that starts where its predecessor ends is joined to it,
+    empty chunks are dropped.  The partitions of a batch are often neighbours in the table
+    (consecutive partition ids, e.g. every evaluation batch and every batch of an unshuffled
+    pass): their rows then form ONE range, which is copied by one launch instead of one per 32
+    chunks -- or not copied at all where a view of the table will do."""
+    offset, count = _host_i64(offset, "Offset"), _host_i64(count, "Count")
+    if offset.numel() != count.numel():
+        raise RuntimeError("Size mismatch")
+    if offset.numel() <= 1 and bool((count != 0).all()):
+        return offset, count
+    o, c = offset.numpy(), count.numpy()
+    keep = c != 0      # (a negative count stays and is refused by the copy)
+    o, c = o[keep], c[keep]
+    if o.size > 1:
+        starts = np.concatenate(([0], np.flatnonzero(o[1:] != o[:-1] + c[:-1]) + 1))
+        o, c = o[starts], np.add.reduceat(c, starts)
+    return torch.from_numpy(np.ascontiguousarray(o)), torch.from_numpy(np.ascontiguousarray(c))
+
+
 def copy_row_chunks(dst: Tensor, src: Tensor, offset: Tensor, count: Tensor,
                     packed_is_src: bool, device=None, relu: bool = False) -> None:
     """Chunked row copy with zero padding (incagg_copy_row_chunks_f32); ``relu``: the copied
-    values pass through ``max(0, .)``."""
+    values pass through ``max(0, .)``.  Chunks that adjoin are copied as one."""
     _rows_f32(dst, "dst")
     _rows_f32(src, "src")
     if not (_device_visible(dst) and _device_visible(src)):
@@ -624,9 +653,9 @@ def copy_row_chunks(dst: Tensor, src: Tensor, offset: Tensor, count: Tensor,
     dev = torch.device(dev)
     if dev.type != "cuda":
         raise RuntimeError("at least one side must be on the GPU")
-    offset, count = _host_i64(offset, "Offset"), _host_i64(count, "Count")
-    if offset.numel() != count.numel():
-        raise RuntimeError("Size mismatch")
+    offset, count = merge_row_chunks(offset, count)
+    if offset.numel() == 0:
+        return
     with _on_device(dev):
         check(lib().incagg_copy_row_chunks_f32(
             _ptr(dst), _ld(dst), dst.size(0), dst.size(1), _ptr(src), _ld(src), src.size(0),

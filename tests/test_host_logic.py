@@ -231,3 +231,26 @@ def test_deferred_activation_gives_the_same_outputs_and_gradients(vr):
     from cpu_shim import cpu_kernels
     with cpu_kernels():
         mc.check_deferred_activation("cpu", vr)
+
+
+def test_merge_row_chunks_joins_neighbours_and_keeps_the_row_order():
+    from torch_geometric_autoscale import ops
+    t = lambda *v: torch.tensor(v, dtype=torch.int64)
+    cases = [
+        ((t(0, 10, 30), t(10, 20, 5)), ([0], [35])),               # all adjoin
+        ((t(0, 12, 30), t(10, 18, 5)), ([0, 12], [10, 23])),       # a gap in front of the second
+        ((t(30, 0, 10), t(5, 10, 20)), ([30, 0], [5, 30])),        # table order != packed order
+        ((t(0, 10, 10, 25), t(10, 0, 15, 5)), ([0], [30])),        # an empty chunk in between
+        ((t(7), t(3)), ([7], [3])),
+        ((t(), t()), ([], [])),
+        ((t(4, 9), t(0, 0)), ([], [])),
+    ]
+    for (off, cnt), (want_o, want_c) in cases:
+        o, c = ops.merge_row_chunks(off, cnt)
+        assert o.dtype == torch.int64 and c.dtype == torch.int64
+        assert o.tolist() == want_o and c.tolist() == want_c
+        # the rows addressed, in order, are unchanged
+        rows = lambda oo, cc: [r for a, n in zip(oo.tolist(), cc.tolist()) for r in range(a, a + n)]
+        assert rows(o, c) == rows(off, cnt)
+    with pytest.raises(RuntimeError, match="Size mismatch"):
+        ops.merge_row_chunks(t(1, 2), t(1))
