@@ -110,6 +110,9 @@ struct SpmmArgs {
   long long ldag;
   const float *add;
   long long ldadd;
+  const float *add2;  // optional second epilogue term: y += add2_scale * add2[i, :]
+  long long ldadd2;
+  float add2_scale;
   float *y;
   long long ldy;
   int n_rows;
@@ -286,6 +289,7 @@ __device__ __forceinline__ void store_row(const SpmmArgs &a, int row, float s,
     if (base) {
       if (INCAGG) out += a.scale * ldv<VEC>(a.m_ag + (size_t)row * a.ldag + off[ch]);
       if (a.add) out += a.add_scale * ldv<VEC>(a.add + (size_t)row * a.ldadd + off[ch]);
+      if (a.add2) out += a.add2_scale * ldv<VEC>(a.add2 + (size_t)row * a.ldadd2 + off[ch]);
     }
     if (a.gate) out = vgate<VEC>(out, ldv<VEC>(a.gate + (size_t)row * a.ldgate + off[ch]));
     float *dst = a.y + (size_t)row * a.ldy + off[ch];
@@ -606,6 +610,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
     if (seg_idx == 0) {
       if (INCAGG) out += a.scale * ld4<ODD>(a.m_ag + (size_t)row * a.ldag + coloff);
       if (a.add) out += a.add_scale * ld4<ODD>(a.add + (size_t)row * a.ldadd + coloff);
+      if (a.add2) out += a.add2_scale * ld4<ODD>(a.add2 + (size_t)row * a.ldadd2 + coloff);
     }
     if (a.gate) out = vgate<4>(out, ld4<ODD>(a.gate + (size_t)row * a.ldgate + coloff));
     float *dst = a.y + (size_t)row * a.ldy + coloff;
@@ -706,6 +711,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
     f4 out = acc * s;
     if (INCAGG) out += a.scale * ld4<ODD>(a.m_ag + (size_t)row * a.ldag + coloff);
     if (a.add) out += a.add_scale * ld4<ODD>(a.add + (size_t)row * a.ldadd + coloff);
+    if (a.add2) out += a.add2_scale * ld4<ODD>(a.add2 + (size_t)row * a.ldadd2 + coloff);
     if (a.gate) out = vgate<4>(out, ld4<ODD>(a.gate + (size_t)row * a.ldgate + coloff));
     st4<ODD>(a.y + (size_t)row * a.ldy + coloff, out);
   }
@@ -956,15 +962,23 @@ extern "C" int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
     INCAGG_REQUIRE(!fuse->gate || fuse->ld_gate >= width, "ld_gate %lld < width %lld",
                    (long long)fuse->ld_gate, (long long)width);
     INCAGG_REQUIRE((const void *)fuse->gate != (const void *)y, "y must not alias gate");
+    INCAGG_REQUIRE(!fuse->add2 || fuse->ld_add2 >= width, "ld_add2 %lld < width %lld",
+                   (long long)fuse->ld_add2, (long long)width);
+    INCAGG_REQUIRE(!fuse->add2 || (const void *)fuse->add2 != (const void *)y,
+                   "y must not alias add2");
     a.relu_x = fuse->relu_x != 0;
     a.gate = fuse->gate;
     a.ldgate = fuse->ld_gate;
+    a.add2 = fuse->add2;
+    a.ldadd2 = fuse->ld_add2;
+    a.add2_scale = fuse->add2_scale;
   }
   rc = error_flag_address(&a.err);
   if (rc) return rc;
   // (widths >= 4 that are not a multiple of 4 qualify too: only the alignment of the rows counts)
   const bool vec4 = width >= 4 && rows_vec4(x, ldx) && rows_vec4(x_halo, ld_halo) &&
-                    rows_vec4(add, ldadd) && rows_vec4(y, ldy) && rows_vec4(a.gate, a.ldgate);
+                    rows_vec4(add, ldadd) && rows_vec4(y, ldy) && rows_vec4(a.gate, a.ldgate) &&
+                    rows_vec4(a.add2, a.ldadd2);
   return dispatch_spmm<false>(a, vec4, plan, static_cast<hipStream_t>(stream));
 }
 

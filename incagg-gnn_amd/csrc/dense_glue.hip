@@ -538,6 +538,41 @@ __global__ __launch_bounds__(256) void gate_add_rows_kernel(float *dst, long lon
   }
 }
 
+// out = scale * (src_0 + src_1 + ... ), every operand with a row pitch of its own: the gradients
+// that the K propagation steps of APPNP hand back for their shared x_0 term summed in one pass
+// (and, with one source, a scaled copy at the output's pitch).
+constexpr int kSumSources = 16;
+struct SumSources {
+  const float *p[kSumSources];
+  long long ld[kSumSources];
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void rows_sum_kernel(const SumSources s, int n, float scale,
+                                                       long long rows, int width, float *out,
+                                                       long long ldo) {
+  const int per_row = width / VEC;
+  const long long total = rows * per_row;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / per_row;
+    const int c = (int)(i - r * per_row) * VEC;
+    if (VEC == 4) {
+      float4 acc = *reinterpret_cast<const float4 *>(s.p[0] + r * s.ld[0] + c);
+      for (int k = 1; k < n; k++) {   // (k is uniform: the pointers come from scalar loads)
+        const float4 v = *reinterpret_cast<const float4 *>(s.p[k] + r * s.ld[k] + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+      *reinterpret_cast<float4 *>(out + r * ldo + c) = acc;
+    } else {
+      float acc = s.p[0][r * s.ld[0] + c];
+      for (int k = 1; k < n; k++) acc += s.p[k][r * s.ld[k] + c];
+      out[r * ldo + c] = acc * scale;
+    }
+  }
+}
+
 // GCNII with separate weights (models/gcn2.py:46-48 through PyG's GCN2Conv):
 //   out = (1 - alpha) (A x) ((1 - beta_l) I + beta_l W1_l) + alpha x_0 ((1 - beta_l) I + beta_l W2_l).
 // The identity parts are folded into the weights of all L layers by one launch:
@@ -622,6 +657,37 @@ extern "C" int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *sr
   else
     hipLaunchKernelGGL((gate_add_rows_kernel<1>), dim3(blocks), dim3(256), 0, s, dst, ldd, src, lds,
                        gate, ldg, rows, (int)width);
+  INCAGG_HIP_TRY(hipGetLastError());
+  return INCAGG_OK;
+}
+
+extern "C" int incagg_rows_sum_f32(const float *const *srcs, const int64_t *lds, int64_t n_srcs,
+                                   float scale, int64_t rows, int64_t width, float *out,
+                                   int64_t ldo, void *stream) {
+  INCAGG_REQUIRE(rows >= 0 && width >= 0 && width < INT_MAX, "bad size");
+  INCAGG_REQUIRE(n_srcs >= 1 && n_srcs <= kSumSources, "%lld sources: 1..%d are supported",
+                 (long long)n_srcs, kSumSources);
+  if (rows == 0 || width == 0) return INCAGG_OK;
+  INCAGG_REQUIRE(srcs && lds && out && ldo >= width, "null pointer or ldo < width");
+  SumSources ss{};
+  bool vec = rows_vec4_ok(out, ldo, width);
+  for (int64_t k = 0; k < n_srcs; k++) {
+    INCAGG_REQUIRE(srcs[k] && lds[k] >= width, "source %lld: null or pitch below the width",
+                   (long long)k);
+    INCAGG_REQUIRE((const void *)srcs[k] != (const void *)out, "out must not alias a source");
+    ss.p[k] = srcs[k];
+    ss.ld[k] = lds[k];
+    vec = vec && rows_vec4_ok(srcs[k], lds[k], width);
+  }
+  const long long items = rows * (width / (vec ? 4 : 1));
+  const int blocks = (int)std::min<long long>((items + 255) / 256, 8192);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec)
+    hipLaunchKernelGGL((rows_sum_kernel<4>), dim3(blocks), dim3(256), 0, s, ss, (int)n_srcs, scale,
+                       rows, (int)width, out, ldo);
+  else
+    hipLaunchKernelGGL((rows_sum_kernel<1>), dim3(blocks), dim3(256), 0, s, ss, (int)n_srcs, scale,
+                       rows, (int)width, out, ldo);
   INCAGG_HIP_TRY(hipGetLastError());
   return INCAGG_OK;
 }

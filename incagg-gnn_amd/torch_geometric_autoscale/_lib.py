@@ -36,6 +36,7 @@ SIGNATURES = {
                                               _vp, _vp]),
     "incagg_set_tuning": (_int, [_c.c_char_p, _int]),
     "incagg_rows_sub_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "incagg_rows_sum_f32": (_int, [_vp, _vp, _i64, _f32, _i64, _i64, _vp, _i64, _vp]),
     "incagg_rows_sub_relu_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp]),
     "incagg_tn_finish_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_tn_finish_batched_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -77,11 +78,12 @@ SIGNATURES = {
 
 class SpmmFuseStruct(_c.Structure):
     """``incagg_spmm_fuse`` of include/incagg_gnn.h."""
-    _fields_ = [("relu_x", _i32), ("gate", _vp), ("ld_gate", _i64)]
+    _fields_ = [("relu_x", _i32), ("gate", _vp), ("ld_gate", _i64),
+                ("add2", _vp), ("ld_add2", _i64), ("add2_scale", _f32)]
 
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class AdamSegment(_c.Structure):

@@ -2,11 +2,12 @@
 tables are ``out_channels`` wide (models/appnp.py:24), in general not a multiple of 4."""
 from typing import Any, Dict, Optional
 
+import torch
 import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import ModuleList
 
-from ..nn import RowsLinear
+from ..nn import RowsLinear, embed_relu, scaled_fan_out
 from .base import ScalableGNN
 
 
@@ -38,10 +39,18 @@ class APPNP(ScalableGNN):
     # ---- hooks (models/appnp.py:141-153)
     def _embed(self, x: Tensor, state: Dict[str, Any], batch_size: int) -> Tensor:
         x = F.dropout(x, p=self.dropout, training=self.training)
-        x = self.lins[0](x).relu()
+        on_gpu = x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+        if on_gpu and self.lins[0].bias is not None:
+            x = embed_relu(self.lins[0], x, 0)[0]      # bias and relu in the GEMM's epilogue
+        else:
+            x = self.lins[0](x).relu()
         x = F.dropout(x, p=self.dropout, training=self.training)
         x = self.lins[1](x)
         state['x_0'] = x[:batch_size]
+        if on_gpu and self.num_layers <= 16:
+            # alpha * x_0 computed once for all propagation steps, its gradient summed over
+            # them in one launch
+            state['x_0_terms'] = scaled_fan_out(state['x_0'], self.alpha, self.num_layers)
         return x
 
     def _update(self, layer: int, agg: Tensor, x: Tensor, state: Dict[str, Any],
@@ -49,6 +58,9 @@ class APPNP(ScalableGNN):
         return (1 - self.alpha) * agg + self.alpha * state['x_0'][:agg.size(0)]
 
     def _mix(self, layer: int, state: Dict[str, Any], batch_size: int):
+        terms = state.get('x_0_terms')
+        if terms is not None:
+            return 1.0 - self.alpha, terms[layer], 1.0
         return 1.0 - self.alpha, state['x_0'], self.alpha
 
     def _update_mixed(self, layer: int, mixed: Tensor, x: Tensor, state: Dict[str, Any]) -> Tensor:

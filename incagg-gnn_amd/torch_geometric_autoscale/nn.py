@@ -415,6 +415,32 @@ class _X0Terms(torch.autograd.Function):
         return dx0, dw, None, None
 
 
+class _ScaledFanOut(torch.autograd.Function):
+    """``scale * x`` handed out ``n`` times, once per consumer (the same memory each time);
+    backward: ``scale`` times the sum of the consumers' gradients in ONE launch -- instead of a
+    multiplication per consumer and autograd's chain of additions."""
+
+    @staticmethod
+    def forward(ctx, x, scale, n):
+        ctx.scale = scale
+        y = ops.rows_sum([x], scale)
+        return tuple(y.data for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        grads = [g if g.stride(-1) == 1 else g.contiguous() for g in grads if g is not None]
+        if not grads:
+            return None, None, None
+        return ops.rows_sum(grads, ctx.scale), None, None
+
+
+def scaled_fan_out(x: Tensor, scale: float, n: int):
+    """``n`` tensors equal to ``scale * x`` for ``n`` consumers that each ADD theirs (APPNP's
+    ``alpha * x_0``, models/appnp.py:85, consumed with ``add_scale = 1``); fp32 [rows, width]
+    on the GPU, ``n <= 16``."""
+    return _ScaledFanOut.apply(x if x.stride(-1) == 1 else x.contiguous(), float(scale), int(n))
+
+
 class RowsLinear(Linear):
     """``torch.nn.Linear`` (same parameters, same state dict) for [rows, features] inputs.
     ``gathered=False``: nothing aggregates over the output (a model's last layer), so it gets

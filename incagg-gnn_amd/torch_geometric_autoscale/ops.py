@@ -237,8 +237,10 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
              reduce: str = "sum", scale: float = 1.0, add: Optional[Tensor] = None,
              add_scale: float = 0.0, out: Optional[Tensor] = None,
              x_halo: Optional[Tensor] = None, plan: Optional[SpmmPlan] = None,
-             relu_x: bool = False, gate: Optional[Tensor] = None) -> Tensor:
-    """y = scale * reduce_rows(A, [x ; x_halo]) + add_scale * add   (incagg_spmm_csr_f32).
+             relu_x: bool = False, gate: Optional[Tensor] = None,
+             add2: Optional[Tensor] = None, add2_scale: float = 0.0) -> Tensor:
+    """y = scale * reduce_rows(A, [x ; x_halo]) + add_scale * add [+ add2_scale * add2]
+    (incagg_spmm_csr_f32).
 
     With ``x_halo`` the source rows ``[x.size(0), n_cols)`` are read from ``x_halo`` -- the
     concatenation is never materialised.  ``plan``: :class:`SpmmPlan` of ``rowptr32``.
@@ -281,13 +283,15 @@ def spmm_csr(rowptr32: Tensor, col32: Tensor, val: Optional[Tensor], x: Tensor, 
             raise ValueError("out has the wrong shape")
     _check_edges(plan, col32)
     fuse = None
-    if relu_x or gate is not None:
-        if gate is not None:
-            _rows_f32(gate, "gate", dev)
-            if gate.size(0) < n_rows or gate.size(1) != width:
-                raise ValueError("gate must be [>= n_rows, width]")
+    if relu_x or gate is not None or add2 is not None:
+        for t, name in ((gate, "gate"), (add2, "add2")):
+            if t is not None:
+                _rows_f32(t, name, dev)
+                if t.size(0) < n_rows or t.size(1) != width:
+                    raise ValueError(f"{name} must be [>= n_rows, width]")
         fuse_struct = _lib.SpmmFuseStruct(1 if relu_x else 0, _ptr(gate),
-                                          0 if gate is None else _ld(gate))
+                                          0 if gate is None else _ld(gate), _ptr(add2),
+                                          0 if add2 is None else _ld(add2), float(add2_scale))
         fuse = ctypes.addressof(fuse_struct)
     with _on_device(dev):
         check(lib().incagg_spmm_csr_f32(
@@ -432,6 +436,30 @@ def relu_rows_(x: Tensor) -> Tensor:
         check(lib().incagg_relu_rows_f32(_ptr(x), _ld(x), x.size(0), x.size(1),
                                          _stream_of(x.device)))
     return x
+
+
+def rows_sum(srcs, scale: float = 1.0) -> Tensor:
+    """``scale * (srcs[0] + srcs[1] + ...)`` over up to 16 [rows, width] matrices of any row
+    pitch in one launch (incagg_rows_sum_f32); the result has the pitch the aggregation wants
+    for its operands (ops.row_pitch)."""
+    srcs = list(srcs)
+    if not 1 <= len(srcs) <= 16:
+        raise ValueError("1 to 16 sources")
+    first = srcs[0]
+    _need_cuda(first, "srcs[0]")
+    for i, t in enumerate(srcs):
+        _rows_f32(t, f"srcs[{i}]", first.device)
+        if t.shape != first.shape:
+            raise ValueError("sources differ in shape")
+    rows, width = first.shape
+    out = rows_empty(rows, width, first.device)
+    ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+    lds = (ctypes.c_int64 * len(srcs))(*[_ld(t) for t in srcs])
+    with _on_device(first.device):
+        check(lib().incagg_rows_sum_f32(ctypes.addressof(ptrs), ctypes.addressof(lds), len(srcs),
+                                        float(scale), rows, width, _ptr(out), _ld(out),
+                                        _stream_of(first.device)))
+    return out
 
 
 def gate_add_rows_(dst: Tensor, src: Tensor, gate: Tensor) -> Tensor:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INCAGG_ABI_VERSION 3
+#define INCAGG_ABI_VERSION 4
 
 enum {
   INCAGG_OK = 0,
@@ -126,11 +126,19 @@ typedef struct incagg_spmm_plan {
  *            models/gcn.py:144-148) applied where its output is consumed instead of in a pass
  *            of its own (History rows are stored activated, see incagg_copy_row_chunks_f32);
  *   gate     (device fp32 [n_rows, width], ld = ld_gate, or NULL): y[i, c] = 0 wherever
- *            gate[i, c] <= 0 -- the backward of that activation, applied to dX = A^T dY. */
+ *            gate[i, c] <= 0 -- the backward of that activation, applied to dX = A^T dY
+ *            (after both epilogue terms). */
 typedef struct incagg_spmm_fuse {
   int32_t relu_x;
   const float *gate;
   int64_t ld_gate;
+  /* a second epilogue term: y[i,:] += add2_scale * add2[i,:] (device fp32 [n_rows, width],
+   * ld = ld_add2, or NULL).  The two-pass incremental aggregate of a model that mixes its
+   * aggregate with x_0 (models/appnp.py:122-130: (1 - alpha) * (A_ib (x - M_in) + M_ag) +
+   * alpha * x_0) passes M_ag as `add` and x_0 here: one launch, no pass over the rows behind. */
+  const float *add2;
+  int64_t ld_add2;
+  float add2_scale;
 } incagg_spmm_fuse;
 
 int incagg_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
@@ -307,6 +315,14 @@ int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float 
 /* x = max(x, 0) in place over [rows, width] (pitch ld): the activation in front of a model's
  * classifier (models/gcn2.py:136), at streaming rate. */
 int incagg_relu_rows_f32(float *x, int64_t ld, int64_t rows, int64_t width, void *stream);
+/* out[i,:] = scale * (srcs[0][i,:] + ... + srcs[n_srcs-1][i,:]) over [rows, width]; srcs / lds:
+ * HOST arrays of n_srcs <= 16 device pointers and their row pitches, consumed before the call
+ * returns.  APPNP's K propagation steps all add alpha * x_0 (models/appnp.py:85): the K
+ * gradients they hand back for that one term are summed and scaled by one launch instead of K
+ * multiplications and K - 1 additions; with one source, a scaled copy at the output's pitch
+ * (alpha * x_0 itself).  No counterpart in the reference (autograd accumulates there). */
+int incagg_rows_sum_f32(const float *const *srcs, const int64_t *lds, int64_t n_srcs, float scale,
+                        int64_t rows, int64_t width, float *out, int64_t ldo, void *stream);
 /* dst[i, c] += src[i, c] wherever gate[i, c] > 0: a relu's backward added onto a gradient that
  * exists already (the x_0 branch of GCNII joining the first layer's gradient), one launch. */
 int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds,

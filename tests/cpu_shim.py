@@ -42,7 +42,8 @@ def _check_plan(plan, rowptr32):
 
 
 def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None, add_scale=0.0,
-              out=None, x_halo=None, plan=None, relu_x=False, gate=None):
+              out=None, x_halo=None, plan=None, relu_x=False, gate=None, add2=None,
+              add2_scale=0.0):
     _check_plan(plan, rowptr32)
     if relu_x:
         x = torch.relu(x)
@@ -53,6 +54,8 @@ def _spmm_csr(rowptr32, col32, val, x, n_cols, reduce="sum", scale=1.0, add=None
     y = torch.from_numpy(y) * scale
     if add is not None:
         y = y + add_scale * add[:y.size(0)]
+    if add2 is not None:
+        y = y + add2_scale * add2[:y.size(0)]
     if gate is not None:
         y = torch.where(gate[:y.size(0)] > 0, y, torch.zeros_like(y))
     if out is not None:

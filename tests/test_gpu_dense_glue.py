@@ -188,3 +188,27 @@ def test_gcn2_weight_fold_matches_the_formulas(ops, dev, n_layers, c):
     assert torch.allclose(ws.grad, ref.grad, rtol=1e-6, atol=1e-7)
     with pytest.raises(ValueError):
         ops.gcn2_fold_weights(ws.detach(), alpha, betas[:-1] if n_layers > 1 else betas + (0.5,))
+
+
+@pytest.mark.parametrize("rows,width", [(116480, 41), (16326, 256), (3, 5), (1, 1)])
+@pytest.mark.parametrize("n", [1, 2, 5, 16])
+def test_rows_sum_matches_torch(ops, dev, rows, width, n):
+    """scale * (s_0 + ... + s_{n-1}) over operands of different row pitches (contiguous,
+    16-byte-aligned padded, unaligned padded); the result has the aggregation's pitch and its
+    padding is not relied on.  fp32 sums in the order of the operands: exact against the same
+    chain in torch."""
+    g = torch.Generator(device=dev).manual_seed(rows + 7 * n)
+    pitches = [width, (width + 15) // 16 * 16 + 32, width + 3]
+    srcs = [torch.randn(rows, pitches[k % 3], device=dev, generator=g)[:, :width] for k in range(n)]
+    got = ops.rows_sum(srcs, 0.1)
+    want = srcs[0].clone()
+    for s in srcs[1:]:
+        want += s
+    want *= 0.1
+    assert got.shape == (rows, width)
+    assert torch.equal(got, want)
+    assert got.stride(0) == ops.row_pitch(width) or rows == 1
+    with pytest.raises(ValueError):
+        ops.rows_sum([])
+    with pytest.raises(ValueError):
+        ops.rows_sum(srcs + [srcs[0][:, :max(width - 1, 0)]])

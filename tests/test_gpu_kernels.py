@@ -192,6 +192,38 @@ def test_spmm_epilogue_and_strides(ops, dev, variant):
     _check(y, y64)
 
 
+@pytest.mark.parametrize("width", [256, 41])
+def test_spmm_second_epilogue_term(ops, dev, width, variant):
+    """y = scale * A x + add_scale * add + add2_scale * add2, then the gate: short rows, rows
+    of one segment and rows cut into several (the terms ride with the first segment only), on
+    padded row pitches; add2 alone; a mis-shaped add2 is refused."""
+    rng = np.random.default_rng(31 + width)
+    n_rows, n_cols = 300, 9000
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, 12, hubs={3: 700, 9: 8800},
+                                  empty_rows=(0, 299))
+    x = rng.standard_normal((n_cols, width)).astype(np.float32)
+    add = rng.standard_normal((n_rows, width)).astype(np.float32)
+    add2 = rng.standard_normal((n_rows + 3, width)).astype(np.float32)
+    gate = rng.standard_normal((n_rows, width)).astype(np.float32)
+    pitch = (width + 15) // 16 * 16 + 32
+    rp, c, v = _dev_csr(rowptr, col, val, dev)
+    (_, xd), (_, ad), (_, a2d), (_, gd) = (_pitched(t, dev, pitch) for t in (x, add, add2, gate))
+    agg = cp.spmm_f64(rowptr, col, val, x)
+    tol = lambda ref: 1e-4 + 1e-4 * np.abs(ref) + 1e-6 * np.sqrt(8800)
+    y = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", 0.9, ad, 0.9, plan=_plan(variant, rp),
+                     add2=a2d, add2_scale=0.1)
+    want = 0.9 * agg + 0.9 * add + 0.1 * add2[:n_rows]
+    assert np.all(np.abs(y.cpu().numpy() - want) <= tol(want))
+    y = ops.spmm_csr(rp, c, v, xd, n_cols, "sum", 0.9, None, 0.0, plan=_plan(variant, rp),
+                     add2=a2d, add2_scale=-2.0, gate=gd)
+    want = np.where(gate > 0, 0.9 * agg - 2.0 * add2[:n_rows], 0.0)
+    assert np.all(np.abs(y.cpu().numpy() - want) <= tol(want))
+    with pytest.raises(ValueError):
+        ops.spmm_csr(rp, c, v, xd, n_cols, "sum", add2=a2d[:n_rows - 1], add2_scale=1.0)
+    from torch_geometric_autoscale import _lib
+    _lib.check_device_errors()
+
+
 def test_spmm_hub_rows_sliced(ops, dev, variant):
     """Rows far beyond the slicing threshold, incl. one that covers every column twice over."""
     rng = np.random.default_rng(11)

@@ -116,6 +116,43 @@ def test_deferred_activation_gives_the_same_outputs_and_gradients(vr, dev):
     mc.check_deferred_activation(dev, vr)
 
 
+@pytest.mark.parametrize("vr", [False, True])
+def test_appnp_shared_term_gradients(vr, dev, monkeypatch):
+    """APPNP hands alpha * x_0 to its propagation steps as one pre-scaled matrix whose gradient is
+    summed over the steps by one launch (and fuses bias + relu of its first linear layer into
+    the GEMM): outputs and every gradient equal those of the plain formulation, in which every
+    step scales x_0 itself and autograd adds the gradients up (models/appnp.py:84-89,122-130)."""
+    from torch_geometric_autoscale.loader import partition_batch
+    from torch_geometric_autoscale.models import APPNP, appnp as appnp_module
+    data, ptr = mc.make_graph()
+    results = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setattr(appnp_module, "scaled_fan_out", lambda x, scale, n: None)
+            monkeypatch.setattr(appnp_module, "embed_relu",
+                                lambda lin, x, n: (lin(x).relu(), None))
+        torch.manual_seed(5)
+        model = APPNP(data.num_nodes, data.x.size(1), 32, 5, 4, alpha=0.1, dropout=0.0,
+                      device=dev).to(dev)
+        gen = torch.Generator().manual_seed(6)
+        for h in list(model.histories) + list(model.histories_ag):
+            h.emb.copy_(torch.randn(h.emb.shape, generator=gen))
+        model.train()
+        sub = partition_batch(data, ptr, [0, 1, 3], in_batch_only=vr)
+        b = sub.batch_size
+        call = model.VR_call if vr else model
+        out = call(sub.data.x.to(dev), sub.data.adj_t.to(dev), b, sub.n_id, sub.offset,
+                   sub.count)["out"]
+        torch.nn.functional.cross_entropy(out, sub.data.y[:b].to(dev)).backward()
+        results.append((out.detach().clone(),
+                        {k: p.grad.clone() for k, p in model.named_parameters()}))
+    (o1, g1), (o2, g2) = results
+    assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-6)
+    assert g1.keys() == g2.keys() and len(g1) == 4
+    for k in g1:
+        assert torch.allclose(g1[k], g2[k], rtol=1e-4, atol=1e-6), k
+
+
 def test_graph_replayed_steps_train_like_eager_steps():
     """Training steps recorded into HIP graphs (one per batch) and replayed leave the model
     where the same steps issued eagerly leave it."""
