@@ -160,6 +160,11 @@ class ScalableGNN(torch.nn.Module):
         push/pull forward uses it; the history tables always hold un-transformed rows)."""
         return None
 
+    def _pre_aggregates(self, layer: int) -> bool:
+        """Whether :meth:`_pre_aggregate` returns a matrix for ``layer`` (its out-of-batch rows
+        must then be pulled and transformed too: they cannot be read in place from the table)."""
+        return type(self)._pre_aggregate is not ScalableGNN._pre_aggregate
+
     def _mix(self, layer: int, state: Dict[str, Any], batch_size: int):
         """Optional ``(scale, add, add_scale)`` to fold into the aggregation epilogue, i.e.
         the layer consumes ``scale * agg + add_scale * add`` (models/appnp.py:85);
@@ -330,7 +335,8 @@ class ScalableGNN(torch.nn.Module):
                 return False
         if not _same_device(history.emb.device, x.device):
             return False
-        if type(self)._pre_aggregate is not ScalableGNN._pre_aggregate:
+        layers = [k for k, h in enumerate(self.histories) if h is history]
+        if not layers or self._pre_aggregates(layers[0]):   # (the layer this table feeds)
             return False
         drops = self.training and self._layer_dropout and getattr(self, "dropout", 0.0) > 0
         return not drops and history.emb.size(1) >= x.size(1)
@@ -341,7 +347,7 @@ class ScalableGNN(torch.nn.Module):
         out-of-batch rows need nothing done to them before they are aggregated."""
         if self.partition_ctx is None or not self.halo_in_place or self.pool is not None:
             return False
-        if type(self)._pre_aggregate is not ScalableGNN._pre_aggregate:
+        if any(self._pre_aggregates(k) for k in range(1, self.num_layers)):
             return False
         if self.training and self._layer_dropout and getattr(self, "dropout", 0.0) > 0:
             return False

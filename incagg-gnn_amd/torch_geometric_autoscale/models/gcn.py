@@ -73,9 +73,12 @@ class GCN(ScalableGNN):
             x = F.dropout(x, p=self.dropout, training=self.training)
         return x
 
-    def _pre_aggregate(self, layer: int, x: Tensor) -> Optional[Tensor]:
+    def _pre_aggregates(self, layer: int) -> bool:
         conv = self.convs[layer]
-        return conv.lin(x) if conv.out_channels < conv.in_channels else None
+        return conv.out_channels < conv.in_channels
+
+    def _pre_aggregate(self, layer: int, x: Tensor) -> Optional[Tensor]:
+        return self.convs[layer].lin(x) if self._pre_aggregates(layer) else None
 
     def _conv_update(self, layer: int, agg: Tensor, x: Tensor, pre: bool) -> Tensor:
         conv = self.convs[layer]

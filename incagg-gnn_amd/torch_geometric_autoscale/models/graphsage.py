@@ -14,6 +14,9 @@ class GraphSAGE(GCN):
     def _make_conv(self, in_dim: int, out_dim: int):
         return SAGEConv(in_dim, out_dim, normalize=False)
 
+    def _pre_aggregates(self, layer: int) -> bool:
+        return False
+
     def _pre_aggregate(self, layer: int, x: Tensor) -> Optional[Tensor]:
         return None  # lin_l follows the mean; the root term needs the untouched input
 
