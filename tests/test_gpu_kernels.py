@@ -652,6 +652,35 @@ def test_spmm_in_place_through_sparse_tensor(dev):
     assert torch.allclose(got2, tga.spmm(adj, x, x_halo=table[other]), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_unaligned_operands_are_realigned(dev, reduce):
+    """A contiguous [rows, 41] source and a contiguous [rows, 41] output gradient (rows that do
+    not start 16-byte aligned) are copied to the padded pitch before they are gathered from:
+    same results as the oracle, forward and backward, and the caller's tensors are untouched."""
+    import torch_geometric_autoscale as tga
+    rng = np.random.default_rng(41)
+    b, m, w = 4500, 6000, 41
+    rowptr, col, val = random_csr(rng, b, m, 9, hubs={3: 900}, empty_rows=(0,),
+                                  weighted=(reduce == "sum"))
+    adj = tga.SparseTensor(rowptr=torch.from_numpy(rowptr), col=torch.from_numpy(col),
+                           value=None if val is None else torch.from_numpy(val),
+                           sparse_sizes=(b, m), is_sorted=True).to(dev)
+    x_np = rng.standard_normal((m, w)).astype(np.float32)
+    dy_np = rng.standard_normal((b, w)).astype(np.float32)
+    x = torch.from_numpy(x_np).to(dev).requires_grad_()
+    assert x.stride(0) % 4 != 0
+    y = tga.spmm(adj, x, reduce)
+    _check(y.detach(), cp.spmm_f64(rowptr, col, val, x_np, reduce))
+    dy = torch.from_numpy(dy_np).to(dev)
+    y.backward(dy)
+    want = cp.spmm_t(rowptr, col, val, dy_np, m, reduce)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    assert torch.equal(x.detach().cpu(), torch.from_numpy(x_np))
+    assert torch.equal(dy.cpu(), torch.from_numpy(dy_np))
+    from torch_geometric_autoscale import _lib
+    _lib.check_device_errors()
+
+
 def test_spmm_single_source_beyond_4gib(ops, dev, variant):
     """One source matrix of more than 4 GiB: row offsets need 64 bits in every kernel variant.
     The oracle runs on the referenced rows only."""
