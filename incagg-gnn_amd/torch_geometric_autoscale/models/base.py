@@ -436,18 +436,16 @@ class ScalableGNN(torch.nn.Module):
             return m_in, m_ag
         if offset is not None and count is not None:
             t_in, t_ag = self.histories[layer], self.histories_ag[layer]
-            if (t_in.emb.is_cuda and t_ag.emb.is_cuda
+            # one range of rows (partitions that are neighbours in the table form one) of
+            # tables that live where the model computes: read where they are (nothing writes
+            # the tables during an incremental-aggregation step)
+            lo = self._batch_range(batch_size, offset, count)
+            if (lo is not None and t_in.emb.is_cuda and t_ag.emb.is_cuda
+                    and lo + batch_size <= min(t_in.emb.size(0), t_ag.emb.size(0))
                     and _same_device(t_in.emb.device, self.device)
                     and _same_device(t_ag.emb.device, self.device)):
-                # one range of rows (partitions that are neighbours in the table form one) of
-                # tables that live where the model computes: read where they are (nothing
-                # writes the tables during an incremental-aggregation step)
-                lo, rows = ops.merge_row_chunks(self._local(offset), count)
-                if lo.numel() == 1 and int(rows[0]) == batch_size:
-                    lo = int(lo[0])
-                    if 0 <= lo and lo + batch_size <= min(t_in.emb.size(0), t_ag.emb.size(0)):
-                        return (t_in.emb[lo:lo + batch_size, :width],
-                                t_ag.emb[lo:lo + batch_size, :width])
+                return (t_in.emb[lo:lo + batch_size, :width],
+                        t_ag.emb[lo:lo + batch_size, :width])
             m_in = t_in.pull_chunks(self._local(offset), count)
             m_ag = t_ag.pull_chunks(self._local(offset), count)
         elif self.partition_ctx is not None:
@@ -457,6 +455,20 @@ class ScalableGNN(torch.nn.Module):
             m_in = self.histories[layer].pull(idx)
             m_ag = self.histories_ag[layer].pull(idx)
         return m_in[:batch_size, :width], m_ag[:batch_size, :width]
+
+    def _batch_range(self, batch_size: int, offset: Tensor, count: Tensor) -> Optional[int]:
+        """First table-local row of a batch whose rows are ONE range of the tables, else None
+        (worked out once per (offset, count) pair: every layer of a step asks)."""
+        key = (id(offset), id(count), batch_size)
+        memo = getattr(self, "_batch_range_memo", None)
+        if memo is not None and memo[0] == key and memo[1] is offset and memo[2] is count:
+            return memo[3]
+        lo, rows = ops.merge_row_chunks(self._local(offset), count)
+        first = int(lo[0]) if lo.numel() == 1 and int(rows[0]) == batch_size else None
+        if first is not None and first < 0:
+            first = None
+        self._batch_range_memo = (key, offset, count, first)
+        return first
 
     def _free_batch_rows(self) -> None:
         if self._async:
