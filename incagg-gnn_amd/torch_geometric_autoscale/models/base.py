@@ -28,7 +28,7 @@ from torch import Tensor
 from .. import ops
 from ..aggregate import incagg_aggregate, spmm
 from ..history import History
-from ..nn import unweighted
+from ..nn import relu_into, unweighted
 from ..pool import AsyncIOPool
 from ..sparse import SparseTensor
 
@@ -504,6 +504,10 @@ class ScalableGNN(torch.nn.Module):
         nid = None if n_id is None else _ids_on(adj_t, n_id, self.emb_device)
         relu_pending = False
         for i in range(self.num_layers):
+            if relu_pending and self._pre_aggregates(i):
+                # this layer aggregates a transformed copy of x: nothing downstream can fold
+                # the activation in (the out-of-batch rows were stored activated)
+                x, relu_pending = relu_into(x), False
             x = self._layer_input(i, x)
             if not use_aggregation:
                 h = self._update(i, x[:b], x, state)

@@ -73,6 +73,14 @@ class GCN(ScalableGNN):
             x = F.dropout(x, p=self.dropout, training=self.training)
         return x
 
+    def _defers_relu(self) -> bool:
+        # the relu at the end of a layer feeds the next aggregation and the History push only:
+        # no batch norm in front of it, no residual or root term reading the layer input (a
+        # subclass with its own update, e.g. GraphSAGE, reads it), no dropout behind it
+        return (type(self)._conv_update is GCN._conv_update and not self.batch_norm
+                and not self.residual and not self.linear
+                and not (self.training and self.dropout > 0))
+
     def _pre_aggregates(self, layer: int) -> bool:
         conv = self.convs[layer]
         return conv.out_channels < conv.in_channels
@@ -94,6 +102,9 @@ class GCN(ScalableGNN):
                 h = self.bns[layer](h)
             if self.residual and h.size(-1) == x.size(-1):
                 h = h + (x if x.size(0) == h.size(0) else x[:h.size(0)])
+            if state.get('defer_relu') and not self.linear:
+                state['relu_deferred'] = True      # applied where h is consumed
+                return h
             h = relu_into(h)
         if layer == self.num_layers - 1 and self.linear:
             h = F.dropout(h, p=self.dropout, training=self.training)

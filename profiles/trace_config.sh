@@ -13,6 +13,6 @@ for l in open('gpurun_out/${tag}_trace.log'):
     if l.startswith('{\"metric\"'):
         d=json.loads(l); print(d['roofline']['launches']//d['steps']); break
 ") || exit 1
-SKIP_TAIL_STEPS=11 python3 profiles/summarize.py gpurun_out/${tag}_trace 10 $per_step > gpurun_out/${tag}_kernel_summary.txt || exit 1
+SKIP_TAIL_STEPS=11 python3 profiles/summarize.py gpurun_out/${tag}_trace 10 $per_step gpurun_out/${tag}_last_step.txt > gpurun_out/${tag}_kernel_summary.txt || exit 1
 rm -rf gpurun_out/${tag}_trace
 head -${TRACE_LINES:-26} gpurun_out/${tag}_kernel_summary.txt

@@ -108,12 +108,13 @@ def test_aggregation_gradients(reduce, dev):
         np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kind", ["gcn2", "gcn"])
 @pytest.mark.parametrize("vr", [False, True])
-def test_deferred_activation_gives_the_same_outputs_and_gradients(vr, dev):
+def test_deferred_activation_gives_the_same_outputs_and_gradients(vr, kind, dev):
     """Push/pull step and incremental-aggregation step with the relu between two layers folded
     into the kernels that consume it, against the same steps with the relu as a pass of its
     own."""
-    mc.check_deferred_activation(dev, vr)
+    mc.check_deferred_activation(dev, vr, kind)
 
 
 @pytest.mark.parametrize("vr", [False, True])

@@ -223,14 +223,15 @@ def test_batched_gcn2_terms_and_fused_embed_have_the_plain_gradients():
         assert torch.allclose(a, b_, rtol=1e-10, atol=1e-10)
 
 
+@pytest.mark.parametrize("kind", ["gcn2", "gcn"])
 @pytest.mark.parametrize("vr", [False, True])
-def test_deferred_activation_gives_the_same_outputs_and_gradients(vr):
+def test_deferred_activation_gives_the_same_outputs_and_gradients(vr, kind):
     """Host orchestration of model_cases.check_deferred_activation (kernels swapped for the
     oracle); the GPU run of the same check is in test_gpu_models.py."""
     import model_cases as mc
     from cpu_shim import cpu_kernels
     with cpu_kernels():
-        mc.check_deferred_activation("cpu", vr)
+        mc.check_deferred_activation("cpu", vr, kind)
 
 
 def test_merge_row_chunks_joins_neighbours_and_keeps_the_row_order():
