@@ -257,6 +257,7 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
     max_steps = max_steps if max_steps != -1 else int(num_parts / batch_size)     # main.py:223
     best_val = final_test = 0.0
     history = []
+    out = None
     y_host = data.y
     for epoch in range(int(params.get("epochs", 1))):
         t0 = time.perf_counter()
@@ -277,7 +278,10 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
             log.info(f"Epoch: {epoch:04d}, Loss: {res['loss']:.4f}, Train: {train_acc:.4f}, "
                      f"Val: {val_acc:.4f}, Test: {test_acc:.4f}, Final: {final_test:.4f}")
     log.info(f"Val: {best_val:.4f}, Test: {final_test:.4f}")
-    return {"history": history, "val": best_val, "test": final_test, "max_steps": max_steps}
+    # (beyond the reference's scores: the trained model, the graph it was trained on and the
+    # output of the last refresh, for callers that go on with them)
+    return {"history": history, "val": best_val, "test": final_test, "max_steps": max_steps,
+            "model": model, "data": data, "out": out}
 
 
 def main(argv=None) -> int:

@@ -59,3 +59,42 @@ def test_driver_with_host_and_device_batch_builders():
         res = train.run(conf)
         assert res["history"][-1]["loss"] < res["history"][0]["loss"], builder
         assert res["val"] > 0.3, (builder, res["val"])
+
+
+@pytest.mark.parametrize("model,vr,extra,kind", [
+    ("GCN2", True, {"alpha": 0.1, "theta": 0.5, "shared_weights": False, "dropout": 0.0}, "gcn2"),
+    ("GCN2", False, {"alpha": 0.1, "theta": 0.5, "shared_weights": False, "dropout": 0.0}, "gcn2"),
+    ("GCN", True, {"dropout": 0.0}, "gcn"),
+    ("GraphSAGE", False, {"dropout": 0.0}, "sage"),
+])
+def test_driver_ends_with_exact_tables_and_outputs(model, vr, extra, kind):
+    """After the driver's last refresh the tables hold the full-graph layer inputs (and, in the
+    incremental mode, their aggregates) of the TRAINED weights and the refresh output is the
+    full-batch output: checked against the numpy model oracle at 1e-4, i.e. training steps
+    (with activations folded into their consumers: no dropout here), table pushes and the
+    layer-wise sweep leave the state the reference's loop defines (main.py:211-215,233-234)."""
+    import numpy as np
+    import model_cases as mc
+    from oracle import model_oracle as mo
+    from torch_geometric_autoscale import train, _lib
+    conf = _conf(model, vr, dict(extra))
+    conf["model"]["params"]["arxiv"]["epochs"] = 2
+    res = train.run(conf)
+    _lib.check_device_errors()
+    net, data = res["model"], res["data"]
+    cfg = dict(ARCH, **extra)
+    rowptr, col, val = (t.numpy() for t in data.adj_t.csr())
+    inputs, aggs, want = mo.full_graph(kind, mc.numpy_state(net), cfg, rowptr, col, val,
+                                       data.x.cpu().numpy())
+    np.testing.assert_allclose(res["out"].numpy(), want, **mc.TOL, err_msg="refresh output")
+    first = 0 if vr else 1          # (the plain sweep does not keep the layer-0 inputs)
+    for i in range(first, net.num_layers):
+        table = net.histories[i]
+        np.testing.assert_allclose(table.emb.cpu().numpy(),
+                                   mo.padded(inputs[i], table.embedding_dim), **mc.TOL,
+                                   err_msg=f"M_in of layer {i}")
+        if vr:
+            table = net.histories_ag[i]
+            np.testing.assert_allclose(table.emb.cpu().numpy(),
+                                       mo.padded(aggs[i], table.embedding_dim), **mc.TOL,
+                                       err_msg=f"M_ag of layer {i}")
