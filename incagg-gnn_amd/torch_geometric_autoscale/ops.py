@@ -84,6 +84,11 @@ def rows_empty(rows: int, width: int, device, dtype=torch.float32, with_base: bo
     of a wider allocation when the pitch differs from the width).  ``with_base``: also the
     contiguous ``[rows, pitch]`` matrix it is a view of."""
     pitch = row_pitch(width) if torch.device(device).type == "cuda" else width
+    if not with_base and pitch != width and rows > 0:
+        # one allocation call instead of allocate + slice + re-wrap (this function runs ~20 times
+        # per eagerly issued step); the storage ends with the last row's last element -- no
+        # kernel touches the padding behind a row
+        return torch.empty_strided((rows, width), (pitch, 1), dtype=dtype, device=device)
     buf = torch.empty((rows, pitch), dtype=dtype, device=device)
     # (.data: same memory, but not a view in autograd's books -- results of custom autograd
     # functions that are views may not be updated in place, e.g. by a following relu_)
