@@ -637,6 +637,35 @@ def _batched_terms(x_0: Tensor, w1f: Tensor, w2cat: Tensor, n_layers: int,
     return _Layers.apply(w1f, dw1, deferred), terms, [deferred.slot(i) for i in range(n_layers)]
 
 
+class _SageUpdate(torch.autograd.Function):
+    """``agg @ W_l^T + b_l + x_root @ W_r^T`` with the second GEMM accumulating into the result
+    of the first (no addition pass, one matrix instead of three) and one backward pass over the
+    incoming gradient for both terms."""
+
+    @staticmethod
+    def forward(ctx, agg, x_root, w_l, b_l, w_r):
+        ctx.save_for_backward(agg, x_root, w_l, w_r)
+        ctx.has_bias = b_l is not None
+        out = ops.rows_empty(agg.size(0), w_l.size(0), agg.device, agg.dtype)
+        if b_l is None:
+            torch.mm(agg, w_l.t(), out=out)
+        else:
+            torch.addmm(b_l, agg, w_l.t(), out=out)
+        return out.addmm_(x_root, w_r.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        agg, x_root, w_l, w_r = ctx.saved_tensors
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        d_agg = _mm_rows(dy, w_l) if need[0] else None
+        d_root = _mm_rows(dy, w_r) if need[1] else None
+        dw_l = _tn_product(dy, agg) if need[2] else None
+        db = _column_sums(dy) if ctx.has_bias and need[3] else None
+        dw_r = _tn_product(dy, x_root) if need[4] else None
+        return d_agg, d_root, dw_l, db, dw_r
+
+
 class SAGEConv(torch.nn.Module):
     """``lin_l(mean_j x_j) + lin_r(x_i)`` (models/graphsage.py:69, spelled out at :623-644)."""
 
@@ -656,6 +685,12 @@ class SAGEConv(torch.nn.Module):
             self.lin_r.reset_parameters()
 
     def update(self, agg: Tensor, x_root: Tensor) -> Tensor:
+        if self.lin_r is not None and agg.is_cuda and agg.dim() == 2 \
+                and agg.dtype == torch.float32 and agg.stride(1) == 1:
+            x_root = x_root if x_root.size(0) == agg.size(0) else x_root[:agg.size(0)]
+            out = _SageUpdate.apply(agg, x_root, self.lin_l.weight, self.lin_l.bias,
+                                    self.lin_r.weight)
+            return torch.nn.functional.normalize(out, p=2.0, dim=-1) if self.normalize else out
         out = self.lin_l(agg)
         if self.lin_r is not None:
             out = out + self.lin_r(x_root if x_root.size(0) == agg.size(0) else x_root[:agg.size(0)])

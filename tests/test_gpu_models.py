@@ -154,6 +154,27 @@ def test_appnp_shared_term_gradients(vr, dev, monkeypatch):
         assert torch.allclose(g1[k], g2[k], rtol=1e-4, atol=1e-6), k
 
 
+def test_sage_fused_update_gradients(dev):
+    """GraphSAGE's update as two GEMMs into one matrix (nn._SageUpdate) against the two linear
+    layers and an addition (models/graphsage.py:623-644): same outputs, same gradients."""
+    from torch_geometric_autoscale.nn import SAGEConv
+    torch.manual_seed(11)
+    conv = SAGEConv(48, 33).to(dev)
+    agg = torch.randn(5000, 48, device=dev, requires_grad=True)
+    x = torch.randn(6000, 48, device=dev, requires_grad=True)
+    dy = torch.randn(5000, 33, device=dev)
+    got = conv.update(agg, x)
+    got.backward(dy)
+    grads = [t.grad.clone() for t in (agg, x, *conv.parameters())]
+    for t in (agg, x, *conv.parameters()):
+        t.grad = None
+    want = conv.lin_l(agg) + conv.lin_r(x[:5000])
+    want.backward(dy)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    for g, t in zip(grads, (agg, x, *conv.parameters())):
+        assert torch.allclose(g, t.grad, rtol=1e-4, atol=1e-4)
+
+
 def test_graph_replayed_steps_train_like_eager_steps():
     """Training steps recorded into HIP graphs (one per batch) and replayed leave the model
     where the same steps issued eagerly leave it."""
