@@ -214,7 +214,11 @@ class _EmbedRelu(torch.autograd.Function):
             # and hands over a buffer of its own: used in place
             g = d_all if d_all.stride(-1) == 1 else d_all.contiguous()
         else:
-            g = torch.ops.aten.threshold_backward(d_all.contiguous(), h, 0)   # new tensor
+            # (a new tensor; a padded row pitch of d_all needs no copy in front)
+            g = torch.ops.aten.threshold_backward(
+                d_all if d_all.stride(-1) == 1 else d_all.contiguous(), h, 0)
+            if g.stride(-1) != 1:
+                g = g.contiguous()
         if d_batch is not None:
             if g.is_cuda and g.dtype == torch.float32 and d_batch.stride(-1) == 1:
                 ops.gate_add_rows_(g[:nb], d_batch, h[:nb])     # one launch instead of two
