@@ -82,6 +82,10 @@ def parse():
     ap.add_argument("--epoch-pass", choices=["auto", "on", "off"], default="auto",
                     help="after the timed steps, time one training pass over ALL of this rank's "
                          "partition batches (auto: single-GPU runs)")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="exercise only the rank launcher: every rank joins a gloo group on the "
+                         "CPU, the ranks all-reduce their numbers and rank 0 prints a JSON line "
+                         "(no GPU needed)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay every step from a HIP graph recorded once per batch "
                          "(auto: on for a single GPU)")
@@ -267,8 +271,74 @@ def cpu_baseline(batches, layers, width, seconds, table_rows):
                       f"optimizer not included; torch CPU ops on {cores} cores, {t_total:.1f} s"}
 
 
+def launch_ranks(n, argv, check_devices=True):
+    """`--gpus N` without a launcher around this script: start N fresh copies of it, one per GPU,
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run
+    would, wait for all of them and return the worst exit code.  The children inherit stdout, so
+    rank 0's JSON line is this command's JSON line.  The parent never touches the GPU (counting
+    devices does not initialise HIP) and a rank that fails takes the others down with it."""
+    import socket
+    import subprocess
+    if check_devices:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have}",
+                  file=sys.stderr, flush=True)
+            return 2
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=env))
+    worst = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            try:
+                rc = procs[r].wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                print(f"bench.py: rank {r} exited with code {rc}; stopping the other ranks",
+                      file=sys.stderr, flush=True)
+                for q in pending:           # (exact PIDs of our own children)
+                    procs[q].terminate()
+    return worst
+
+
+def launch_selftest(args):
+    """The launcher's contract on a machine without GPUs: every rank sees its environment, the
+    ranks meet over gloo, rank 0 prints one JSON line."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    if os.environ.get("BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": float(t),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "gpus_flag": args.gpus}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], check_devices=not args.launch_selftest))
+    if args.launch_selftest:
+        return launch_selftest(args)
     # Only the JSON line may reach stdout: communication libraries print banners there.
     # Everything else this process (and its native libraries) writes goes to stderr.
     sys.stdout.flush()
@@ -277,7 +347,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, this machine shows "
+                 f"{torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_dist

@@ -1,7 +1,12 @@
 """Worker of tests/test_distributed_cpu.py: one rank of a partition-parallel run on the CPU
 (gloo).  The HIP entry points are swapped for the CPU oracle (tests/cpu_shim.py), so what
 is exercised is the sharding, the halo plans, the all-to-all routing and the gradient
-all-reduce.  Launched with torch.distributed.run; writes its results to argv[1]."""
+all-reduce.  Launched with torch.distributed.run; writes its results to argv[1].
+
+With DIST_WORKER_DEVICE=cuda (tests/test_gpu_distributed.py) the same script is one rank of a
+run on the GPUs: backend "nccl" (RCCL), rank r on GPU LOCAL_RANK, the real HIP entry points,
+tables in HBM."""
+import contextlib
 import os
 import sys
 
@@ -22,15 +27,28 @@ def main():
     out_dir = sys.argv[1]
     names = sys.argv[2].split(",")
     in_place = len(sys.argv) > 3 and sys.argv[3] == "in_place"
-    dist.init_process_group("gloo")
+    on_gpu = os.environ.get("DIST_WORKER_DEVICE", "cpu") == "cuda"
+    if on_gpu:
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo")
     from torch_geometric_autoscale import distributed as D
     data, ptr = mc.make_graph()
-    ctx = D.PartitionContext(ptr)
+    ctx = D.PartitionContext(ptr, exercise_collectives=on_gpu and dist.get_world_size() == 1)
     result = {"row_lo": ctx.row_lo, "row_hi": ctx.row_hi}
-    with cpu_kernels():
+
+    def to_dev(t):
+        return t.to(dev) if on_gpu else t
+
+    with (contextlib.nullcontext() if on_gpu else cpu_kernels()):
         for name in names:
-            model = mc.make_model(name, data, data.x.size(1), 5, emb_device="cpu",
+            model = mc.make_model(name, data, data.x.size(1), 5, emb_device=dev if on_gpu else "cpu",
                                   num_nodes=ctx.local_rows)
+            if on_gpu:
+                model = model.to(dev)
             model.set_partition_context(ctx)
             model.eval()
             batches = D.sharded_eval_batches(data, ptr, ctx, batch_size=1)
@@ -57,9 +75,10 @@ def main():
             # push/pull forward + backward on this rank's first partition, then the all-reduce
             sub = D.sharded_partition_batch(data, ptr, [ctx.part_lo], ctx)
             b = sub.batch_size
-            ret = model(sub.data.x, sub.data.adj_t, b, sub.n_id, sub.offset, sub.count)
+            x_dev, adj_dev, y_dev = to_dev(sub.data.x), to_dev(sub.data.adj_t), to_dev(sub.data.y[:b])
+            ret = model(x_dev, adj_dev, b, sub.n_id, sub.offset, sub.count)
             result[f"{name}/gas_out"] = ret["out"].detach().clone()
-            loss = torch.nn.functional.cross_entropy(ret["out"], sub.data.y[:b])
+            loss = torch.nn.functional.cross_entropy(ret["out"], y_dev)
             model.zero_grad()
             loss.backward()
             D.allreduce_gradients(model, ctx)
@@ -70,13 +89,12 @@ def main():
                 # the table tails), then a forward that contains no collective, gradients into
                 # one flat buffer, one all-reduce of that buffer
                 flat = D.flatten_gradients(model)
-                for pending in model.start_halo_exchanges(sub.data.adj_t):
+                for pending in model.start_halo_exchanges(adj_dev):
                     pending.wait()
-                ret2 = model(sub.data.x, sub.data.adj_t, b, sub.n_id, sub.offset, sub.count,
-                             halo_ready=True)
+                ret2 = model(x_dev, adj_dev, b, sub.n_id, sub.offset, sub.count, halo_ready=True)
                 assert torch.allclose(ret2["out"], ret["out"], rtol=1e-5, atol=1e-6)
                 model.zero_grad(set_to_none=False)
-                torch.nn.functional.cross_entropy(ret2["out"], sub.data.y[:b]).backward()
+                torch.nn.functional.cross_entropy(ret2["out"], y_dev).backward()
                 D.allreduce_flat_gradients(flat, ctx)
                 # the flat buffer holds the same all-reduced mean gradient (zeros where a
                 # parameter got no gradient, which the list of the first run leaves out)
@@ -88,13 +106,18 @@ def main():
                     p.grad = None
             # incremental-aggregation step: no halo traffic at all
             sub = D.sharded_partition_batch(data, ptr, [ctx.part_lo], ctx, in_batch_only=True)
-            ret = model.VR_call(sub.data.x, sub.data.adj_t, sub.batch_size, sub.n_id, sub.offset,
-                                sub.count)
+            ret = model.VR_call(to_dev(sub.data.x), to_dev(sub.data.adj_t), sub.batch_size, sub.n_id,
+                                sub.offset, sub.count)
             result[f"{name}/vr_out"] = ret["out"].detach().clone()
             if in_place:
                 result[f"{name}/calls"] = dict(calls)
                 for attr, fn in originals.items():
                     setattr(D.HaloPlan, attr, fn)
+    if on_gpu:
+        from torch_geometric_autoscale import _lib
+        torch.cuda.synchronize()
+        _lib.check_device_errors()
+        result = {k: v.cpu() if torch.is_tensor(v) else v for k, v in result.items()}
     torch.save(result, os.path.join(out_dir, f"rank{ctx.rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -18,6 +18,63 @@ NAMES = ["gcn2", "sage", "appnp"]
 TOL = dict(rtol=1e-4, atol=1e-4)
 
 
+def check_against_single_process(ranks, world, dev=None):
+    """The per-rank results of tests/dist_worker.py against one process working on the whole
+    graph: on the CPU through the oracle kernels, or (``dev``) on a GPU through the HIP path."""
+    import contextlib
+    from torch_geometric_autoscale.loader import partition_batch
+    import torch_geometric_autoscale as tga
+    data, ptr = mc.make_graph()
+    n_parts = ptr.numel() - 1
+    on_gpu = dev is not None
+
+    def to_dev(t):
+        return t.to(dev) if on_gpu else t
+
+    def host(t):
+        return t.detach().cpu().numpy()
+
+    with (contextlib.nullcontext() if on_gpu else cpu_kernels()):
+        for name in NAMES:
+            model = mc.make_model(name, data, data.x.size(1), 5, emb_device=dev if on_gpu else "cpu")
+            if on_gpu:
+                model = model.to(dev)
+            model.eval()
+            loader = tga.EvalSubgraphLoader(data, ptr, batch_size=1, log=False)
+            out = model.mini_inference_vr(loader)
+            grads, cover = [], []
+            for r, res in enumerate(ranks):
+                lo, hi = res["row_lo"], res["row_hi"]
+                cover.append((lo, hi))
+                np.testing.assert_allclose(res[f"{name}/out"].numpy(), host(out[lo:hi]), **TOL)
+                for i in range(model.num_layers):
+                    np.testing.assert_allclose(res[f"{name}/hist{i}"].numpy(),
+                                               host(model.histories[i].emb[lo:hi]), **TOL)
+                    np.testing.assert_allclose(res[f"{name}/hist_ag{i}"].numpy(),
+                                               host(model.histories_ag[i].emb[lo:hi]), **TOL)
+                part = r * n_parts // world
+                sub = partition_batch(data, ptr, [part])
+                b = sub.batch_size
+                ret = model(to_dev(sub.data.x), to_dev(sub.data.adj_t), b, sub.n_id, sub.offset,
+                            sub.count)
+                np.testing.assert_allclose(res[f"{name}/gas_out"].numpy(), host(ret["out"]), **TOL)
+                loss = torch.nn.functional.cross_entropy(ret["out"], to_dev(sub.data.y[:b]))
+                model.zero_grad()
+                loss.backward()
+                grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()
+                                        if p.grad is not None]).cpu())
+                sub = partition_batch(data, ptr, [part], in_batch_only=True)
+                ret = model.VR_call(to_dev(sub.data.x), to_dev(sub.data.adj_t), sub.batch_size,
+                                    sub.n_id, sub.offset, sub.count)
+                np.testing.assert_allclose(res[f"{name}/vr_out"].numpy(), host(ret["out"]), **TOL)
+            assert cover[0][0] == 0 and cover[-1][1] == data.num_nodes
+            assert all(a[1] == b_[0] for a, b_ in zip(cover, cover[1:]))
+            mean_grad = torch.stack(grads).mean(0).numpy()
+            for res in ranks:                      # identical on every rank after the all-reduce
+                np.testing.assert_allclose(res[f"{name}/grad"].numpy(), mean_grad, rtol=1e-4,
+                                           atol=1e-6 if not on_gpu else 1e-5)
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -41,48 +98,7 @@ def test_sharded_run_matches_single_process(world, mode, tmp_path):
         for res in ranks:
             assert res["gcn2/calls"]["in_place"] > 0 and res["gcn2/calls"]["buffer"] == 0, res["gcn2/calls"]
 
-    from torch_geometric_autoscale.loader import partition_batch
-    import torch_geometric_autoscale as tga
-    data, ptr = mc.make_graph()
-    n_parts = ptr.numel() - 1
-    with cpu_kernels():
-        for name in NAMES:
-            model = mc.make_model(name, data, data.x.size(1), 5, emb_device="cpu")
-            model.eval()
-            loader = tga.EvalSubgraphLoader(data, ptr, batch_size=1, log=False)
-            out = model.mini_inference_vr(loader)
-            grads, cover = [], []
-            for r, res in enumerate(ranks):
-                lo, hi = res["row_lo"], res["row_hi"]
-                cover.append((lo, hi))
-                np.testing.assert_allclose(res[f"{name}/out"].numpy(), out[lo:hi].numpy(), **TOL)
-                for i in range(model.num_layers):
-                    np.testing.assert_allclose(res[f"{name}/hist{i}"].numpy(),
-                                               model.histories[i].emb[lo:hi].numpy(), **TOL)
-                    np.testing.assert_allclose(res[f"{name}/hist_ag{i}"].numpy(),
-                                               model.histories_ag[i].emb[lo:hi].numpy(), **TOL)
-                part = r * n_parts // world
-                sub = partition_batch(data, ptr, [part])
-                b = sub.batch_size
-                ret = model(sub.data.x, sub.data.adj_t, b, sub.n_id, sub.offset, sub.count)
-                np.testing.assert_allclose(res[f"{name}/gas_out"].numpy(),
-                                           ret["out"].detach().numpy(), **TOL)
-                loss = torch.nn.functional.cross_entropy(ret["out"], sub.data.y[:b])
-                model.zero_grad()
-                loss.backward()
-                grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()
-                                        if p.grad is not None]))
-                sub = partition_batch(data, ptr, [part], in_batch_only=True)
-                ret = model.VR_call(sub.data.x, sub.data.adj_t, sub.batch_size, sub.n_id,
-                                    sub.offset, sub.count)
-                np.testing.assert_allclose(res[f"{name}/vr_out"].numpy(),
-                                           ret["out"].detach().numpy(), **TOL)
-            assert cover[0][0] == 0 and cover[-1][1] == data.num_nodes
-            assert all(a[1] == b_[0] for a, b_ in zip(cover, cover[1:]))
-            mean_grad = torch.stack(grads).mean(0).numpy()
-            for res in ranks:                      # identical on every rank after the all-reduce
-                np.testing.assert_allclose(res[f"{name}/grad"].numpy(), mean_grad, rtol=1e-4,
-                                           atol=1e-6)
+    check_against_single_process(ranks, world)
 
 
 def test_halo_plan_orders_own_rows_first():

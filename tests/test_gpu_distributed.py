@@ -3,7 +3,10 @@ collectives issued although they move nothing): process-group set-up on the GPU,
 `all_to_all_single` on device tensors, stream ordering of the pending exchange, the flat gradient
 all-reduce -- against the unsharded run of the same model.  Tables in HBM and in pinned host
 memory (BASELINE configuration 5's placement)."""
+import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -188,3 +191,54 @@ def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
     for h, g in zip(model.histories, eager.histories):
         np.testing.assert_allclose(h.emb.cpu().numpy(), g.emb.cpu().numpy(), **TOL)
     _lib.check_device_errors()
+
+
+def _run_gpu_ranks(world, mode, tmp_path):
+    """`world` fresh processes of tests/dist_worker.py, rank r on GPU r, backend "nccl"."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, DIST_WORKER_DEVICE="cuda", RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(root, "tests", "dist_worker.py"), str(tmp_path),
+             "gcn2,sage,appnp", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+            text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r}:\n" + outs[r][-3000:]
+    return [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+
+
+@pytest.mark.parametrize("mode", ["buffer", "in_place"])
+def test_one_rank_worker_over_rccl_matches_single_process(mode, tmp_path):
+    """The multi-rank worker itself, started as ONE fresh process on GPU 0 (collectives forced
+    on): what the two-rank test below runs, on a machine with a single GPU."""
+    from test_distributed_cpu import check_against_single_process
+    ranks = _run_gpu_ranks(1, mode, tmp_path)
+    check_against_single_process(ranks, 1, dev=torch.device("cuda", 0))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("mode", ["buffer", "in_place"])
+def test_two_ranks_over_rccl_match_single_process(mode, tmp_path):
+    """Two RCCL ranks, one per GPU: row-sharded tables after the refresh sweep, the push/pull
+    forward of each rank's first partition, the incremental-aggregation forward and the
+    all-reduced gradient equal what one process computes on the whole graph."""
+    from test_distributed_cpu import check_against_single_process
+    ranks = _run_gpu_ranks(2, mode, tmp_path)
+    for res in ranks:
+        if mode == "in_place":
+            assert res["gcn2/calls"]["in_place"] > 0 and res["gcn2/calls"]["buffer"] == 0
+    check_against_single_process(ranks, 2, dev=torch.device("cuda", 0))
