@@ -23,9 +23,12 @@ does), and recording / replaying interleaved with eager *training steps* is fine
 that alternate training epochs with eager sweeps (``train.run``) therefore issue their steps
 eagerly.
 """
-from typing import Callable, Dict, Hashable
+import logging
+from typing import Callable, Dict, Hashable, Optional
 
 import torch
+
+log = logging.getLogger("incagg.graphs")
 
 
 class StepGraphs:
@@ -69,3 +72,84 @@ class StepGraphs:
 
     def __contains__(self, key: Hashable) -> bool:
         return key in self.graphs
+
+
+class SweepGraph:
+    """A whole refresh sweep -- ``mini_inference`` / ``mini_inference_vr`` over a FIXED list of
+    evaluation batches (models/gcn2.py:433-507) -- recorded once as one HIP graph and replayed
+    with a single call per epoch.  A sweep is ``batches x layers`` rounds of aggregation, dense
+    update and one or two History pushes, 6-10 launches each, issued from Python: on MI355X the
+    host needs longer to issue a round than the GPU to run it.  Evaluation batches are static
+    (loader.py:266-284), the tables and parameters keep their addresses, so the launch sequence
+    is the same every epoch.
+
+    The first call runs the sweep eagerly on the capture stream (that IS the first sweep: tables
+    and output are filled; every lazily built per-batch structure and the device copies of the
+    batches' features come into being) and then records it; later calls replay.  Only for
+    models whose tables live where they compute, without staging pools and outside a partition
+    context -- anything else, and any failure to record, leaves the sweep to be issued eagerly
+    (``recorded`` tells which).  The model is switched to evaluation mode for the sweep and
+    back afterwards."""
+
+    def __init__(self, model, loader, with_aggregates: bool = True, use_aggregation: bool = True,
+                 graphs: Optional[StepGraphs] = None):
+        self.model = model
+        self.batches = list(loader)
+        self.with_aggregates, self.use_aggregation = with_aggregates, use_aggregation
+        self.graphs = graphs
+        self.key = ("sweep", id(self))
+        self.recorded = False
+        self.calls = 0
+        dev = torch.device(model.device)
+        self.supported = (
+            dev.type == "cuda" and model.pool is None and model.partition_ctx is None
+            and model.emb_device.type == "cuda"
+            and (model.emb_device.index or 0) == (dev.index or torch.cuda.current_device()))
+
+    def _sweep(self):
+        return self.model._sweep(self.batches, self.use_aggregation, self.with_aggregates)
+
+    def _resident(self) -> bool:
+        """Whether every batch's features are in HBM (a recording cannot copy from the host)."""
+        dev = torch.device(self.model.device)
+        for sub in self.batches:
+            data = sub[0]
+            x = data.x
+            if x.is_cuda:
+                continue
+            kept = data.__dict__.get("_x_on_device", {})
+            if not any(d.type == "cuda" and (d.index or 0) == (dev.index or 0) for d in kept):
+                return False
+        return True
+
+    def __call__(self):
+        model = self.model
+        was_training = model.training
+        model.eval()
+        try:
+            self.calls += 1
+            if self.recorded:
+                self.graphs.replay(self.key)
+                return model._out
+            if not self.supported:
+                return self._sweep()
+            if self.graphs is None:
+                self.graphs = StepGraphs(model.device)
+            out = None
+
+            def eager():
+                nonlocal out
+                out = self._sweep()
+            self.graphs.warm(eager, times=1)
+            if not self._resident():
+                self.supported = False
+                return out
+            try:
+                self.graphs.capture(self.key, self._sweep)
+                self.recorded = True
+            except Exception as exc:    # the sweep stays eager
+                self.supported = False
+                log.warning("recording the refresh sweep failed (%r); it is issued eagerly", exc)
+            return out
+        finally:
+            model.train(was_training)

@@ -143,6 +143,12 @@ class DeviceSubgraphLoader:
     def __len__(self) -> int:
         return -(-self.num_parts // self.batch_size)
 
+    @property
+    def static_batches(self) -> bool:
+        """Whether a group of partitions always comes back as the SAME batch object (steps over
+        such batches can be recorded once and replayed)."""
+        return self._cache is not None
+
     def _build(self, parts) -> SubData:
         if self._cache is None:
             return device_partition_batch(self.data, self.ptr, parts, self.device, self.in_batch_only)

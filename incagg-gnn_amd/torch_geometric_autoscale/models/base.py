@@ -683,9 +683,15 @@ class ScalableGNN(torch.nn.Module):
         # [rows, layers * width] matrix per batch, i.e. about one more set of tables
         keep_terms = False
         if self.device.type == 'cuda' and not use_pool:
-            rows = sum(b[1] for b in batches)
-            need = rows * self.num_layers * self.histories[-1].embedding_dim * 4
-            keep_terms = need < 0.4 * torch.cuda.mem_get_info(self.device)[0]
+            if torch.cuda.is_current_stream_capturing():
+                # (a recording repeats the decision of the eager sweep that preceded it: the
+                # driver is not asked for its free memory inside a recording)
+                keep_terms = bool(getattr(self, "_sweep_keeps_terms", False))
+            else:
+                rows = sum(b[1] for b in batches)
+                need = rows * self.num_layers * self.histories[-1].embedding_dim * 4
+                keep_terms = need < 0.4 * torch.cuda.mem_get_info(self.device)[0]
+                self._sweep_keeps_terms = keep_terms
 
         def ids_on_device(data, n_id):     # one upload per (static) evaluation batch
             return _ids_on(data.adj_t, n_id, self.device)
@@ -721,7 +727,7 @@ class ScalableGNN(torch.nn.Module):
                 continue
             adj_t = data.adj_t.to(self.device)
             state['keep_layer_terms'] = keep_terms
-            x = self._embed(data.x.to(self.device), state, batch_size)
+            x = self._embed(_features_on(data, self.device), state, batch_size)
             if with_aggregates:
                 if x.size(1) > self.histories[0].embedding_dim:
                     raise ValueError(
@@ -813,6 +819,28 @@ def _ids_on(holder, n_id: Tensor, device) -> Tensor:
     if hit is None or hit[0] is not n_id or hit[2] != n_id._version:
         hit = kept[device] = (n_id, n_id.to(device), n_id._version)
     return hit[1]
+
+
+def _features_on(data, device) -> Tensor:
+    """``data.x`` on ``device``.  Features of a (static) evaluation batch that live on the host
+    are uploaded once, through pinned memory, and kept on the batch -- every later sweep over the
+    same batch object reads the resident copy (no host-to-device copy per sweep, and nothing a
+    recorded sweep would have to copy from the host) -- as long as HBM has ample room for them;
+    otherwise they are uploaded per use."""
+    x = data.x
+    device = torch.device(device)
+    if x.device == device or device.type != "cuda" or (x.is_cuda and device.index is None):
+        return x.to(device)
+    kept = data.__dict__.setdefault("_x_on_device", {})
+    hit = kept.get(device)
+    if hit is not None and hit[0] is x and hit[2] == x._version:
+        return hit[1]
+    staged = x if x.is_cuda or x.is_pinned() else x.pin_memory()
+    # (torch's pinned-memory allocator keeps the staging block until the transfer is over)
+    on_dev = staged.to(device, non_blocking=True)
+    if x.numel() * x.element_size() * 16 < torch.cuda.mem_get_info(device)[0]:
+        kept[device] = (x, on_dev, x._version)
+    return on_dev
 
 
 def _same_device(a, b) -> bool:

@@ -42,6 +42,10 @@ DEFAULTS: Dict[str, Any] = {
     # "device": graph, features and labels live in HBM and batches are built there by the HIP
     # batch builder (needs a GPU); "host": the reference's DataLoader path (loader.py:95-284)
     "batch_builder": "auto",
+    # HIP graphs: training steps over static batches (built once and kept by the loader) and the
+    # refresh sweep are recorded at their first execution and replayed from then on.  "auto": on
+    # a GPU with the History tables in HBM.
+    "graphs": "auto",
     "dataset": {"name": "arxiv"},
     "model": {"name": "GCN", "norm": True, "loop": True, "params": {}},
 }
@@ -50,11 +54,23 @@ DEFAULTS: Dict[str, Any] = {
 def mini_train(model, loader, criterion, optimizer, max_steps, grad_norm=None, edge_dropout=0.0,
                epoch=0, VR_update=False, period_updates_in_one_epoch=0, ptr=None, debug_flag=False,
                period_update_trigger=None, drift_norm=2, aggregate_combined=True,
-               use_aggregation=True):
+               use_aggregation=True, graphs=None):
     """One training epoch (main.py:47-96).  Batches without training nodes are skipped; the
-    loss is averaged over training nodes; the epoch stops after ``max_steps`` batches."""
+    loss is averaged over training nodes; the epoch stops after ``max_steps`` batches.
+
+    ``graphs`` (a ``graphs.StepGraphs``): with a loader that keeps its batch objects
+    (``static_batches``) and no edge dropout, the step of a batch -- forward, loss, backward,
+    gradient clipping, optimizer step, loss bookkeeping -- is recorded into a HIP graph right
+    after its first (eager) execution and replayed whenever the batch comes up again."""
     model.train()
     total_loss, total_examples = 0.0, 0     # the loss sum stays on the device until the end
+    replayable = (graphs is not None and getattr(loader, "static_batches", False)
+                  and not edge_dropout and torch.device(model.device).type == "cuda")
+    if replayable:
+        total_loss = graphs.__dict__.get("_loss_sum")
+        if total_loss is None:
+            total_loss = graphs.__dict__["_loss_sum"] = torch.zeros((), device=model.device)
+        total_loss.zero_()
     for i, (batch, batch_size, n_id, offset, count) in enumerate(loader):
         x = batch.x.to(model.device)
         adj_t = batch.adj_t.to(model.device)
@@ -71,21 +87,36 @@ def mini_train(model, loader, criterion, optimizer, max_steps, grad_norm=None, e
         train_idx = batch.__dict__["_train_idx"]
         adj_t = dropout(adj_t, p=edge_dropout)
 
-        if VR_update:
-            ret = model.VR_call(x, adj_t, batch_size, n_id, offset, count, debug_flag=debug_flag,
-                                drift_norm=drift_norm, epoch=epoch, batch_idx=i)
+        def step(x=x, adj_t=adj_t, y=y, train_idx=train_idx, batch_size=batch_size, n_id=n_id,
+                 offset=offset, count=count, i=i):
+            if VR_update:
+                ret = model.VR_call(x, adj_t, batch_size, n_id, offset, count,
+                                    debug_flag=debug_flag, drift_norm=drift_norm, epoch=epoch,
+                                    batch_idx=i)
+            else:
+                ret = model(x, adj_t, batch_size, n_id, offset, count, drift_norm=drift_norm,
+                            aggregate_combined=aggregate_combined,
+                            use_aggregation=use_aggregation)
+            out = ret['out']
+            optimizer.zero_grad()
+            loss = criterion(out.index_select(0, train_idx), y.index_select(0, train_idx))
+            loss.backward()
+            if grad_norm is not None:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
+            optimizer.step()
+            return loss.detach()
+
+        if replayable:
+            key = ("train-step", id(batch), bool(VR_update))    # (the loader keeps `batch` alive)
+            if key in graphs:
+                graphs.replay(key)
+            else:
+                def counted(step=step, n_train=n_train):
+                    total_loss.add_(step() * n_train)
+                graphs.warm(counted, times=1)       # the step itself, issued eagerly ...
+                graphs.capture(key, counted)        # ... and its recording (runs nothing)
         else:
-            ret = model(x, adj_t, batch_size, n_id, offset, count, drift_norm=drift_norm,
-                        aggregate_combined=aggregate_combined, use_aggregation=use_aggregation)
-        out = ret['out']
-        optimizer.zero_grad()
-        loss = criterion(out.index_select(0, train_idx), y.index_select(0, train_idx))
-        loss.backward()
-        if grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
-        optimizer.step()
-        loss = loss.detach()
-        total_loss = total_loss + loss * n_train
+            total_loss = total_loss + step() * n_train
         total_examples += n_train
         # the epoch may stop early so that the tables get refreshed (main.py:90-92)
         if (i + 1) >= max_steps and (i + 1) < len(loader):
@@ -244,11 +275,36 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
         optimizer = torch.optim.Adam(groups, lr=params.get("lr", 0.01))
     use_agg = bool(conf["use_aggregation"])
 
+    use_graphs = conf["graphs"]
+    if use_graphs == "auto":
+        use_graphs = device.type == "cuda" and hist_dev is not None and model.pool is None
+    step_graphs = sweep_graph = None
+    if use_graphs:
+        from .graphs import StepGraphs, SweepGraph
+        step_graphs = StepGraphs(device)
+        sweep_graph = SweepGraph(model, eval_loader, with_aggregates=vr, use_aggregation=use_agg,
+                                 graphs=step_graphs)
+    # the refresh output travels to the host through ONE pinned buffer (no pageable copies
+    # between replays of recorded work)
+    out_host = None
+
     def refresh():
         model.eval()
+        if sweep_graph is not None:
+            return sweep_graph()
         if vr:
             return model.mini_inference_vr(loader=eval_loader, use_aggregation=use_agg)
         return model.mini_inference(loader=eval_loader, use_aggregation=use_agg)
+
+    def to_host(t):
+        nonlocal out_host
+        if not t.is_cuda:
+            return t
+        if out_host is None or out_host.shape != t.shape or out_host.dtype != t.dtype:
+            out_host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        out_host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return out_host
 
     t = time.perf_counter()
     refresh()                                                                      # main.py:211-215
@@ -263,9 +319,10 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
         t0 = time.perf_counter()
         res = mini_train(model, train_loader, criterion, optimizer, max_steps, grad_norm,
                          edge_dropout, epoch, VR_update=vr, ptr=ptr, drift_norm=conf["drift_norm"],
-                         aggregate_combined=bool(conf["aggregate_combined"]), use_aggregation=use_agg)
+                         aggregate_combined=bool(conf["aggregate_combined"]), use_aggregation=use_agg,
+                         graphs=step_graphs)
         t1 = time.perf_counter()
-        out = refresh().cpu()
+        out = to_host(refresh())
         t2 = time.perf_counter()
         train_acc = compute_micro_f1(out, y_host, data.train_mask)
         val_acc = compute_micro_f1(out, y_host, data.val_mask)
@@ -281,7 +338,10 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
     # (beyond the reference's scores: the trained model, the graph it was trained on and the
     # output of the last refresh, for callers that go on with them)
     return {"history": history, "val": best_val, "test": final_test, "max_steps": max_steps,
-            "model": model, "data": data, "out": out}
+            "model": model, "data": data, "out": None if out is None else out.clone(),
+            "graphs": {"train_steps_recorded": 0 if step_graphs is None else sum(
+                           1 for k in step_graphs.graphs if k[0] == "train-step"),
+                       "sweep_recorded": bool(sweep_graph is not None and sweep_graph.recorded)}}
 
 
 def main(argv=None) -> int:
