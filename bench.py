@@ -560,6 +560,27 @@ def main():
         opt.step()
         return bt["edges"]
 
+    # The refresh sweep (timed after the steps): its evaluation batches, resident in HBM, and on
+    # a single GPU its recording -- the first call issues the sweep eagerly (the tables then
+    # hold real layer inputs and aggregates) and records it, BEFORE any step is recorded.
+    evals = sweep_graph = None
+    if args.sweep == "on" or (args.sweep == "auto" and not sharded):
+        feat = tga.Data(adj_t=data.adj_t, num_nodes=n)
+        if sharded:
+            evals = D.sharded_eval_batches(feat, ptr, ctx)
+        else:
+            evals = [partition_batch(feat, ptr, grp) for grp in groups]
+        for sub in evals:                       # features of each batch resident in HBM
+            if sub.batch_size:
+                sub.data.x = x_all[sub.n_id.to(dev)]
+                sub.data.adj_t.to(dev)
+        if not sharded and not host_tables and args.graphs != "off":
+            from torch_geometric_autoscale.graphs import SweepGraph
+            sweep_graph = SweepGraph(model, evals, with_aggregates=True)
+            sweep_graph()
+            model.train()
+            torch.cuda.synchronize()
+
     # Edges per step, counted once per batch in an instrumented eager step: every aggregation
     # launch adds the edges its rows address (forward launches the batch adjacency; backward
     # launches the transposed adjacency, restricted to in-batch source rows where the
@@ -709,27 +730,24 @@ def main():
     # ---- epoch time, part (ii): one layer-wise refresh sweep over every partition
     # (outside the timed region above; it is reported next to the headline value)
     sweep_s = sweep_edges = None
-    if args.sweep == "on" or (args.sweep == "auto" and not sharded):
-        model.eval()
-        feat = tga.Data(adj_t=data.adj_t, num_nodes=n)
-        if sharded:
-            evals = D.sharded_eval_batches(feat, ptr, ctx)
-        else:
-            evals = [partition_batch(feat, ptr, grp) for grp in groups]
-        for sub in evals:                       # features of each batch resident in HBM
-            if sub.batch_size:
-                sub.data.x = x_all[sub.n_id.to(dev)]
-                sub.data.adj_t.to(dev)
+    sweep_launch = None
+    if evals is not None:
         torch.cuda.synchronize()
         if sharded:
             dist.barrier()
         t0 = time.perf_counter()
-        model.mini_inference_vr(evals)
+        if sweep_graph is not None:
+            sweep_graph()
+        else:
+            model.eval()
+            model.mini_inference_vr(evals)
         torch.cuda.synchronize()
         if sharded:
             dist.barrier()
         sweep_s = time.perf_counter() - t0
         sweep_edges = args.layers * sum(sub.data.adj_t.nnz() for sub in evals)
+        sweep_launch = ("one HIP graph replay" if sweep_graph is not None and sweep_graph.recorded
+                        else "eager")
         _lib.check_device_errors()
 
     ks = clock.summary()
@@ -768,6 +786,7 @@ def main():
                 "train_epoch_batches": len(groups),
                 "refresh_sweep_seconds": sweep_s,
                 "refresh_sweep_edges_per_s": None if not sweep_s else sweep_edges / sweep_s,
+                "refresh_sweep_launch": sweep_launch,
                 "note": "training epoch = one measured pass over all of this rank's partition "
                         "batches (when train_epoch_measured; else batches x step time); the sweep is "
                         "one mini_inference_vr over this rank's partitions (forward only, both "

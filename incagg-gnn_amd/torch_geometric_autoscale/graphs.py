@@ -14,14 +14,15 @@ builds every lazily built per-batch structure (transposed CSR, work plans, in-pl
 outside the recording.  Tensors a recorded step reads -- batch arrays, plans and their combine
 buffers, History tables, parameters -- must stay alive and keep their addresses.
 
-Known limitation (observed on ROCm 7.0 / torch 2.10 with an earlier build of the library; cause
-not established, and not re-tested since): replaying recorded steps AFTER other work had been
-issued eagerly on the device since the recording -- a refresh sweep between two epochs of replays
--- ended in an illegal memory access, while the same graphs replay indefinitely when nothing
-eager runs in between (warm everything, record everything, then only replay: what ``bench.py``
-does), and recording / replaying interleaved with eager *training steps* is fine too.  Loops
-that alternate training epochs with eager sweeps (``train.run``) therefore issue their steps
-eagerly.
+Envelope the recordings are used in (and tested in, tests/test_gpu_train_graphs.py): once
+steps have been recorded, the device only sees replays (steps and the recorded refresh sweep,
+:class:`SweepGraph`), eagerly issued *training steps*, and small host<->device transfers through
+pinned memory.  An earlier build of the library showed an illegal memory access when recorded
+steps were replayed after an EAGERLY issued refresh sweep; the cause was never established (the
+library kept mutable device state across launches then, which it no longer does), so that
+sequence is refused instead of run: :meth:`StepGraphs.replay` raises when an eager sweep has been
+issued since the step was recorded.  Loops that alternate training epochs with refresh sweeps
+(``train.run``) record the sweep too, which also makes the sweep host-free.
 """
 import logging
 from typing import Callable, Dict, Hashable, Optional
@@ -30,6 +31,14 @@ import torch
 
 log = logging.getLogger("incagg.graphs")
 
+_eager_sweeps = 0
+
+
+def note_eager_sweep() -> None:
+    """Called by the models whenever a refresh sweep is issued eagerly (not being recorded)."""
+    global _eager_sweeps
+    _eager_sweeps += 1
+
 
 class StepGraphs:
     def __init__(self, device):
@@ -37,6 +46,7 @@ class StepGraphs:
         self.stream = torch.cuda.Stream(self.device)
         self.pool = torch.cuda.graph_pool_handle()
         self.graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
+        self._sweeps_at_capture: Dict[Hashable, int] = {}
 
     def warm(self, fn: Callable[[], None], times: int = 2) -> None:
         """Runs ``fn`` eagerly on the capture stream (lazy initialisation happens here)."""
@@ -66,8 +76,14 @@ class StepGraphs:
                 sys.stderr.flush()
                 raise
         self.graphs[key] = graph
+        self._sweeps_at_capture[key] = _eager_sweeps
 
     def replay(self, key: Hashable) -> None:
+        if self._sweeps_at_capture[key] != _eager_sweeps:
+            raise RuntimeError(
+                "a refresh sweep has been issued eagerly since this step was recorded; replaying "
+                "recorded steps after an eager sweep is not supported (record the sweep with "
+                "graphs.SweepGraph, or record the steps again)")
         self.graphs[key].replay()
 
     def __contains__(self, key: Hashable) -> bool:

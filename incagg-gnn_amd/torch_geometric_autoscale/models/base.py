@@ -658,6 +658,9 @@ class ScalableGNN(torch.nn.Module):
 
     @torch.no_grad()
     def _sweep(self, loader, use_aggregation: bool, with_aggregates: bool) -> Tensor:
+        if self.device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+            from ..graphs import note_eager_sweep
+            note_eager_sweep()      # (recorded steps are not replayed after an eager sweep)
         holders = [m for m in self.modules() if hasattr(m, "hold_folded_weights")]
         for m in holders:       # weights are constant for the duration of a sweep
             m.hold_folded_weights(True)

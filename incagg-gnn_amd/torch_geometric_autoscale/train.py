@@ -289,9 +289,13 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
     out_host = None
 
     def refresh():
+        nonlocal step_graphs
         model.eval()
         if sweep_graph is not None:
-            return sweep_graph()
+            out = sweep_graph()
+            if not sweep_graph.recorded:    # sweeps stay eager: then so do the steps
+                step_graphs = None
+            return out
         if vr:
             return model.mini_inference_vr(loader=eval_loader, use_aggregation=use_agg)
         return model.mini_inference(loader=eval_loader, use_aggregation=use_agg)

@@ -15,8 +15,11 @@ conf = {"seed": 0, "dataset": {"name": "products"}, "batch_size": 1, "VR_update"
                              "batch_norm": False, "residual": False, "shared_weights": False,
                              "alpha": 0.1, "theta": 0.5},
             "num_parts": parts, "max_steps": -1, "pool_size": 1, "num_workers": 0, "lr": 0.001,
-            "reg_weight_decay": 0, "nonreg_weight_decay": 0, "grad_norm": None, "epochs": 3}}}}
+            "reg_weight_decay": 0, "nonreg_weight_decay": 0, "grad_norm": None, "epochs": int(os.environ.get("EPOCHS", "4"))}}}}
+if os.environ.get("GRAPHS"):
+    conf["graphs"] = os.environ["GRAPHS"] == "1"
 res = train.run(conf)
 _lib.check_device_errors()
+print(json.dumps(res["graphs"]), flush=True)
 for h in res["history"]:
     print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in h.items()}), flush=True)
