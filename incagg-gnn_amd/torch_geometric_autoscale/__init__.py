@@ -34,7 +34,7 @@ from .data import Data, get_data, gcn_norm, synthetic_graph  # noqa: E402
 from .history import History  # noqa: E402
 from .pool import AsyncIOPool  # noqa: E402
 from .metis import metis, permute  # noqa: E402
-from .utils import compute_micro_f1, dropout  # noqa: E402
+from .utils import compute_micro_f1, dropout, gen_masks, index2mask  # noqa: E402
 from .loader import (SubgraphLoader, EvalSubgraphLoader, DeviceSubgraphLoader, SubData,  # noqa: E402
                      partition_batch, device_partition_batch)
 from .aggregate import spmm, incagg_aggregate  # noqa: E402
@@ -45,7 +45,7 @@ __version__ = '0.1.0'
 
 __all__ = [
     'SparseTensor', 'Data', 'get_data', 'gcn_norm', 'synthetic_graph', 'History', 'AsyncIOPool',
-    'metis', 'permute', 'compute_micro_f1', 'dropout',
+    'metis', 'permute', 'compute_micro_f1', 'dropout', 'gen_masks', 'index2mask',
     'SubgraphLoader', 'EvalSubgraphLoader', 'SubData', 'spmm', 'incagg_aggregate', 'models',
     '__version__',
 ]

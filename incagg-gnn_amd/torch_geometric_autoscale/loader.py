@@ -44,24 +44,32 @@ class SubData(NamedTuple):
 def sample_neighbors(src: SparseTensor, num_neighbors: int,
                      unsampled_n_id: Tensor = None) -> Tuple[SparseTensor, Tensor]:
     """Keeps at most ``num_neighbors`` random edges per row, columns in their original
-    order (loader.py:32-93); ``num_neighbors < 0`` keeps everything."""
+    order (loader.py:32-93); ``num_neighbors < 0`` keeps everything.  The node ids are
+    returned unchanged: out-of-batch nodes that lost all their edges keep their columns.
+    Runs where ``src`` lives (a batch built on the GPU is sampled there, and the result is
+    again a device-format adjacency)."""
     if num_neighbors < 0:
         return src, unsampled_n_id
     rowptr, col, value = src.csr()
+    dev = col.device
     deg = rowptr[1:] - rowptr[:-1]
     # random key per edge; keep the `num_neighbors` smallest of every row, order preserved
-    key = torch.rand(col.numel())
+    key = torch.rand(col.numel(), device=dev, dtype=torch.float64)
     row = src.storage.row()
-    order = torch.argsort(row.to(torch.float64) + key.to(torch.float64) * 0.999999, stable=True)
+    order = torch.argsort(row.to(torch.float64) + key * 0.999999, stable=True)
     rank = torch.empty_like(order)
-    rank[order] = torch.arange(order.numel())
+    rank[order] = torch.arange(order.numel(), device=dev)
     keep = (rank - rowptr[row]) < num_neighbors
     new_deg = torch.minimum(deg, torch.full_like(deg, num_neighbors))
     new_rowptr = torch.zeros_like(rowptr)
     new_rowptr[1:] = torch.cumsum(new_deg, 0)
-    out = SparseTensor(rowptr=new_rowptr, col=col[keep],
-                       value=None if value is None else value[keep],
-                       sparse_sizes=src.sparse_sizes(), is_sorted=True)
+    new_val = None if value is None else value[keep]
+    if dev.type == "cuda":
+        out = SparseTensor.from_device_csr(new_rowptr.to(torch.int32), col[keep].to(torch.int32),
+                                           new_val, src.sparse_sizes())
+    else:
+        out = SparseTensor(rowptr=new_rowptr, col=col[keep], value=new_val,
+                           sparse_sizes=src.sparse_sizes(), is_sorted=True)
     return out, unsampled_n_id
 
 
@@ -134,10 +142,13 @@ class DeviceSubgraphLoader:
     and in-place column ids, which hang off the adjacency object."""
 
     def __init__(self, data: Data, ptr: Tensor, device, batch_size: int = 1, shuffle: bool = False,
-                 in_batch_only: bool = False):
+                 in_batch_only: bool = False, num_neighbors: int = -1):
         self.data, self.ptr, self.device = data, ptr, torch.device(device)
         self.batch_size, self.shuffle, self.in_batch_only = batch_size, shuffle, in_batch_only
         self.num_parts = ptr.numel() - 1
+        # per-row neighbour sampling (loader.py:217-246): a fresh sample of the kept batch at
+        # every visit, drawn on the GPU; such batches are never the same object twice
+        self.num_neighbors = -1 if num_neighbors is None else int(num_neighbors)
         self._cache = {} if (not shuffle or batch_size == 1) else None
 
     def __len__(self) -> int:
@@ -147,7 +158,15 @@ class DeviceSubgraphLoader:
     def static_batches(self) -> bool:
         """Whether a group of partitions always comes back as the SAME batch object (steps over
         such batches can be recorded once and replayed)."""
-        return self._cache is not None
+        return self._cache is not None and self.num_neighbors < 0
+
+    def _sampled(self, sub: SubData) -> SubData:
+        if self.num_neighbors < 0:
+            return sub
+        adj_t, n_id = sample_neighbors(sub.data.adj_t, self.num_neighbors, sub.n_id)
+        out = sub.data.__class__(**{k: v for k, v in sub.data if k != "adj_t"})
+        out.adj_t = adj_t
+        return SubData(out, sub.batch_size, n_id, sub.offset, sub.count)
 
     def _build(self, parts) -> SubData:
         if self._cache is None:
@@ -161,7 +180,7 @@ class DeviceSubgraphLoader:
     def __iter__(self):
         order = torch.randperm(self.num_parts).tolist() if self.shuffle else list(range(self.num_parts))
         for i in range(0, self.num_parts, self.batch_size):
-            yield self._build(order[i:i + self.batch_size])
+            yield self._sampled(self._build(order[i:i + self.batch_size]))
 
 
 class SubgraphLoader(DataLoader):

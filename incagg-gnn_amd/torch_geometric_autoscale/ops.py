@@ -585,7 +585,9 @@ def softmax_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """Mean softmax cross entropy of ``logits`` [rows, classes] against int64 ``labels`` [rows]
     -- ``torch.nn.CrossEntropyLoss()`` with its defaults (main.py:60,78) -- as two launches
     forward and one backward (incagg_softmax_xent_*_f32).  Labels outside ``[0, classes)`` are
-    reported by ``check_device_errors``."""
+    reported by ``check_device_errors`` -- torch's ``ignore_index`` (-100) included: rows to be
+    left out of the loss are selected away before the call, as the training loop does with its
+    mask (main.py:80)."""
     _need_cuda(logits, "logits")
     _rows_f32(logits, "logits")
     if labels.dtype != torch.int64 or labels.dim() != 1 or labels.numel() != logits.size(0) \
@@ -663,10 +665,12 @@ def merge_row_chunks(offset: Tensor, count: Tensor) -> Tuple[Tensor, Tensor]:
     offset, count = _host_i64(offset, "Offset"), _host_i64(count, "Count")
     if offset.numel() != count.numel():
         raise RuntimeError("Size mismatch")
-    if offset.numel() <= 1 and bool((count != 0).all()):
+    if offset.numel() <= 1 and bool((count > 0).all()):
         return offset, count
     o, c = offset.numpy(), count.numpy()
-    keep = c != 0      # (a negative count stays and is refused by the copy)
+    if (c < 0).any():   # refused here: joined to a neighbour it would pass for a shorter chunk
+        raise RuntimeError("Invalid index: negative row count")
+    keep = c != 0
     o, c = o[keep], c[keep]
     if o.size > 1:
         starts = np.concatenate(([0], np.flatnonzero(o[1:] != o[:-1] + c[:-1]) + 1))

@@ -79,6 +79,7 @@ class SparseTensor:
         self._row: Optional[Tensor] = None
         self._host: Optional["SparseTensor"] = None   # CPU original of a GPU copy
         self._transposed = {}                         # reduce -> (rowptr32, col32, val)
+        self._t_shared = {}                           # structure of the transposed CSR (see set_value)
         self._max_row_nnz: Optional[int] = None
         self.storage = _Storage(self)
 
@@ -99,6 +100,7 @@ class SparseTensor:
         out._row = None
         out._host = None
         out._transposed = {}
+        out._t_shared = {}
         out._max_row_nnz = None
         out.storage = _Storage(out)
         return out
@@ -199,6 +201,7 @@ class SparseTensor:
             out._row = None
             out._host = self if self._device.type == "cpu" else self._host
             out._transposed = {}
+            out._t_shared = {}
             out._max_row_nnz = self.max_row_nnz()
             # the aggregation's work plan is part of batch construction: built on the host
             # from the row pointers, uploaded with them
@@ -223,11 +226,16 @@ class SparseTensor:
 
     # ------------------------------------------------------------------ edits (host-side graph prep)
     # What a copy with other edge values may share with its source: sizes, index arrays and
-    # everything derived from the STRUCTURE alone.  Everything that holds values (transposed
-    # CSR, uploaded copies, the in-batch view, the value-less view) is rebuilt on demand.
+    # everything derived from the STRUCTURE alone -- the work plans, the in-place column ids, and
+    # the index arrays of the transposed CSR together with the permutation that carries edge
+    # values into its order (``_t_shared``).  Everything that holds values (transposed values,
+    # packed edge lists, uploaded copies, the in-batch view, the value-less view) is rebuilt on
+    # demand: edge dropout on a weighted adjacency (utils.py:62-68, applied at every training
+    # step, main.py:68) then costs one gather of the new values and the re-packing of the edge
+    # lists, not a transposition and not a plan.
     _STRUCTURE_KEYS = ("_sizes", "_device", "_rowptr_i64", "_col_i64", "_rowptr_i32", "_col_i32",
                        "_row", "_max_row_nnz", "_plans", "_in_place_cols", "_halo_plan",
-                       "_ids_on_device")
+                       "_ids_on_device", "_t_shared")
 
     def set_value(self, value: Optional[Tensor], layout: Optional[str] = None) -> "SparseTensor":
         out = SparseTensor.__new__(SparseTensor)
@@ -402,6 +410,20 @@ class SparseTensor:
         key = "mean" if reduce == "mean" else "sum"
         if key not in self._transposed:
             n_r, n_c = self._sizes
+            shared = self.__dict__.setdefault("_t_shared", {})
+            if key == "sum" and shared.get("csr") is not None and self._device.type == "cuda":
+                # an adjacency that shares its structure with one transposed before (a copy with
+                # other edge values): only the values are carried over, in the transposed order
+                # (edges sorted by column, ties in storage order)
+                t_rowptr, t_col = shared["csr"]
+                if self._value is None:
+                    t_val = torch.ones(t_col.numel(), dtype=torch.float32, device=self._device)
+                else:
+                    if "perm" not in shared:
+                        shared["perm"] = torch.argsort(self._col32(), stable=True)
+                    t_val = self._value.to(torch.float32).index_select(0, shared["perm"])
+                self._transposed[key] = (t_rowptr, t_col, t_val)
+                return self._transposed[key]
             windows = {(0, n_c), (0, min(n_r, n_c))}
             plans = self.__dict__.setdefault("_plans", {})
             if self._host is None and self._device.type == "cuda":
@@ -409,6 +431,8 @@ class SparseTensor:
                 t_rowptr, t_col, t_val = ops.csr_transpose_device(
                     self._rowptr32(), self._col32(), self._value, n_r, n_c, key)
                 self._transposed[key] = (t_rowptr, t_col, t_val)
+                if key == "sum":
+                    shared["csr"] = (t_rowptr, t_col)
                 for lo, hi in windows:
                     plans[("t", lo, hi)] = ops.SpmmPlan.build(t_rowptr[lo:hi + 1], self.nnz())
                 return self._transposed[key]
@@ -417,6 +441,8 @@ class SparseTensor:
             t_rowptr, t_col, t_val = ops.csr_transpose(rowptr, col, value, n_r, n_c, key)
             dev = self._device
             self._transposed[key] = (t_rowptr.to(dev), t_col.to(dev), t_val.to(dev))
+            if key == "sum" and dev.type == "cuda":
+                shared["csr"] = self._transposed[key][:2]
             if dev.type == "cuda":
                 for lo, hi in windows:
                     plans[("t", lo, hi)] = ops.SpmmPlan.build(t_rowptr[lo:hi + 1],

@@ -240,15 +240,17 @@ def run(conf: Dict[str, Any]) -> Dict[str, Any]:
     vr = bool(conf["VR_update"])
     loader_data = data.__class__(**{k: v for k, v in data if k != "ptr"})
     builder = conf["batch_builder"]
-    if builder == "auto":   # neighbour sampling is host-side only
-        builder = "device" if device.type == "cuda" and conf["num_neighbors"] in (-1, None) \
-            else "host"
+    if builder == "auto":
+        builder = "device" if device.type == "cuda" else "host"
     if builder == "device":
         dev_data = loader_data.__class__(**{
             k: (v.to(device) if isinstance(v, torch.Tensor) and k != "adj_t" else v)
             for k, v in loader_data})
+        # (like the reference's collate choice, loader.py:187-188: sampling applies to the
+        # one-hop batches of the push/pull step only)
         train_loader = DeviceSubgraphLoader(dev_data, ptr, device, batch_size=batch_size,
-                                            shuffle=True, in_batch_only=vr)
+                                            shuffle=True, in_batch_only=vr,
+                                            num_neighbors=-1 if vr else conf["num_neighbors"])
         eval_loader = DeviceSubgraphLoader(dev_data, ptr, device, batch_size=batch_size)
     else:
         train_loader = SubgraphLoader(loader_data, ptr, batch_size=batch_size, shuffle=True,

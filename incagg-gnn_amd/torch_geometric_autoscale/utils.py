@@ -1,12 +1,40 @@
-"""The two helpers of the reference's utils.py that the training driver needs: the score
-(utils.py:15-35) and random edge dropout (utils.py:62-73).  Dataset-split helpers of that
-file are not part of this package."""
-from typing import Optional
+"""The helpers of the reference's utils.py: ``index2mask`` (utils.py:9-12), the score
+(utils.py:15-35), random per-class splits (utils.py:38-59) and random edge dropout
+(utils.py:62-73)."""
+from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
 
 from .sparse import SparseTensor
+
+
+def index2mask(idx: Tensor, size: int) -> Tensor:
+    """Boolean mask of length ``size`` that is set at ``idx`` (utils.py:9-12)."""
+    mask = torch.zeros(size, dtype=torch.bool, device=idx.device)
+    mask[idx] = True
+    return mask
+
+
+def gen_masks(y: Tensor, train_per_class: int = 20, val_per_class: int = 30,
+              num_splits: int = 20) -> Tuple[Tensor, Tensor, Tensor]:
+    """``num_splits`` random splits, one per column of the ``[N, num_splits]`` masks: of every
+    class ``train_per_class`` training and ``val_per_class`` validation nodes, the rest is the
+    test set (utils.py:38-59)."""
+    n, num_classes = y.size(0), int(y.max()) + 1
+    train_mask = torch.zeros(n, num_splits, dtype=torch.bool)
+    val_mask = torch.zeros(n, num_splits, dtype=torch.bool)
+    columns = torch.arange(num_splits)
+    for c in range(num_classes):
+        members = (y == c).nonzero(as_tuple=False).reshape(-1)
+        # one shuffled copy of the class per split, side by side
+        shuffled = torch.stack([members[torch.randperm(members.numel())]
+                                for _ in range(num_splits)], dim=1)
+        picked = shuffled[:train_per_class]
+        train_mask[picked, columns.expand_as(picked)] = True
+        picked = shuffled[train_per_class:train_per_class + val_per_class]
+        val_mask[picked, columns.expand_as(picked)] = True
+    return train_mask, val_mask, ~(train_mask | val_mask)
 
 
 def compute_micro_f1(logits: Tensor, y: Tensor, mask: Optional[Tensor] = None) -> float:

@@ -300,7 +300,9 @@ int incagg_softmax_xent_backward_f32(const float *logits, int64_t ld, const int6
  *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = *step + 1.
  * Every tensor has its own step count (device fp32, starts at 0; as in torch, a tensor that is
  * left out of a call does not age), read and advanced on the device, so a recorded launch keeps
- * counting when replayed.  segs: HOST array; entries with n == 0 are skipped. */
+ * counting when replayed.  segs: HOST array; entries with n == 0 are skipped.  A step count may
+ * be shared by several segments only when they all fall into the same group of 24 consecutive
+ * entries (a shared count is advanced once per group): give every segment its own count. */
 typedef struct incagg_adam_segment {
   float *p;        /* parameters, updated in place */
   const float *g;  /* gradients */

@@ -234,20 +234,36 @@ def check_training_step(name, model, data, ptr, device, vr):
     return float(loss.detach())
 
 
-def check_step_gradients(name, model, data, ptr, device, vr, parts=(1, 3)):
+def check_step_gradients(name, model, data, ptr, device, vr, parts=(1, 3), num_neighbors=-1,
+                         edge_dropout=0.0):
     """Loss, output and EVERY weight gradient of one training step (push/pull, or incremental
     aggregation with ``vr``) against float64 autograd over the layer formulas
     (oracle/grad_oracle.py) with the table contents the step reads; tolerance 1e-4 relative to
     the largest entry of each gradient.  Dropout off, batch norm (where the case has it) on batch
-    statistics."""
-    from torch_geometric_autoscale.loader import partition_batch
+    statistics.
+
+    ``num_neighbors`` / ``edge_dropout``: the batch adjacency is first sampled per row
+    (loader.py:217-246) and / or put through random edge dropout (utils.py:62-73, main.py:68),
+    on ``device``, exactly as the training loop does; the oracle then works on the adjacency
+    that came out."""
+    from torch_geometric_autoscale.loader import partition_batch, sample_neighbors
+    from torch_geometric_autoscale.utils import dropout
     case = MODEL_CASES[name]
     model.train()
     sub = partition_batch(data, ptr, list(parts), in_batch_only=vr)
     b = sub.batch_size
     n_id = sub.n_id
     sd = numpy_state(model)
-    rp, c, v = (t.numpy() for t in sub.data.adj_t.csr())
+    adj = sub.data.adj_t.to(device)
+    if num_neighbors >= 0:
+        adj, n_id = sample_neighbors(adj, num_neighbors, n_id)
+        assert adj.sparse_sizes() == sub.data.adj_t.sparse_sizes()
+        assert int(adj.storage.rowcount().max()) <= num_neighbors
+    if edge_dropout:
+        before = adj
+        adj = dropout(adj, p=edge_dropout)
+        assert adj is not before and adj.nnz() <= before.nnz()
+    rp, c, v = (None if t is None else t.cpu().numpy() for t in adj.csr())
     y = sub.data.y[:b]
     extra = {}
     if vr:
@@ -259,8 +275,7 @@ def check_step_gradients(name, model, data, ptr, device, vr, parts=(1, 3)):
                                                   sub.data.x.numpy(), b, y.numpy(), **extra)
     model.zero_grad(set_to_none=True)
     call = model.VR_call if vr else model
-    out = call(sub.data.x.to(device), sub.data.adj_t.to(device), b, n_id, sub.offset,
-               sub.count)["out"]
+    out = call(sub.data.x.to(device), adj, b, n_id, sub.offset, sub.count)["out"]
     loss = torch.nn.functional.cross_entropy(out, y.to(device))
     loss.backward()
     np.testing.assert_allclose(out.detach().cpu().numpy(), want_out, **TOL,

@@ -78,6 +78,68 @@ def test_staged_pull_mode_matches_zero_copy(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["gcn2", "sage", "appnp", "gcn", "gcn2_headline"])
+def test_sampled_and_edge_dropped_batches_through_the_hip_step(name, dev):
+    """Neighbour sampling (loader.py:217-246) and random edge dropout (utils.py:62-73, applied
+    to the device adjacency at every step, main.py:68) in front of the HIP training step:
+    output, loss and every weight gradient against the float64 step oracle on the adjacency
+    that came out of the sampling / the dropout."""
+    from torch_geometric_autoscale import _lib
+    data, ptr, n_cls = mc.case_graph(name)
+    model = mc.make_model(name, data, data.x.size(1), n_cls, emb_device=dev).to(dev)
+    mc.check_refresh_sweep(name, model, data, ptr)
+    torch.manual_seed(11)
+    mc.check_step_gradients(name, model, data, ptr, dev, vr=False, num_neighbors=4)
+    mc.check_step_gradients(name, model, data, ptr, dev, vr=False, edge_dropout=0.3)
+    mc.check_step_gradients(name, model, data, ptr, dev, vr=True, edge_dropout=0.3)
+    mc.check_step_gradients(name, model, data, ptr, dev, vr=False, num_neighbors=6,
+                            edge_dropout=0.2)
+    _lib.check_device_errors()
+
+
+@pytest.mark.parametrize("built_on", ["host", "device"])
+def test_weighted_edge_dropout_keeps_the_cached_structure(built_on, dev):
+    """Dropout on a weighted adjacency only changes edge values (utils.py:66-68): the copy
+    shares the work plans, the in-place column ids and the index arrays of the transposed CSR
+    with its source, and its transposed VALUES -- carried over by the cached permutation --
+    equal those of a transposition from scratch, element for element."""
+    import torch_geometric_autoscale as tga
+    from torch_geometric_autoscale import ops
+    from torch_geometric_autoscale.loader import device_partition_batch, partition_batch
+    from torch_geometric_autoscale.utils import dropout
+    data, ptr = mc.make_graph()
+    if built_on == "host":
+        adj = partition_batch(data, ptr, [1, 4]).data.adj_t.to(dev)
+    else:
+        adj = device_partition_batch(data, ptr, [1, 4], dev).data.adj_t
+    n_r, n_c = adj.sparse_sizes()
+    t_rowptr, t_col, t_val = adj.device_csr_t("sum")
+    plan, plan_t = adj.plan(), adj.plan_t("sum", 0, n_r)
+    torch.manual_seed(3)
+    for _ in range(2):
+        dropped = dropout(adj, p=0.4)
+        assert dropped is not adj and dropped.nnz() == adj.nnz()
+        value = dropped.storage.value()
+        assert float((value == 0).float().mean()) > 0.2
+        d_rowptr, d_col, d_val = dropped.device_csr_t("sum")
+        assert d_rowptr is t_rowptr and d_col is t_col
+        assert dropped.plan().order is plan.order
+        assert dropped.plan_t("sum", 0, n_r).order is plan_t.order
+        rp32, c32, _ = dropped.device_csr()
+        f_rowptr, f_col, f_val = ops.csr_transpose_device(rp32, c32, value, n_r, n_c, "sum")
+        assert torch.equal(f_rowptr, d_rowptr) and torch.equal(f_col, d_col)
+        assert torch.equal(f_val, d_val)
+        # and the aggregation over the dropped copy, forward and backward, follows its values
+        x = torch.randn(n_c, 24, device=dev, requires_grad=True)
+        dy = torch.randn(n_r, 24, device=dev)
+        tga.spmm(dropped, x).backward(dy)
+        rp, c, v = (t.cpu().numpy() for t in dropped.csr())
+        want = cp.spmm_t(rp, c, v, dy.cpu().numpy(), n_c)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # the source is untouched
+    assert torch.equal(adj.device_csr_t("sum")[2], t_val)
+
+
 @pytest.mark.parametrize("reduce", ["sum", "mean"])
 def test_aggregation_gradients(reduce, dev):
     """dX of spmm and of the incremental aggregate against the oracle's A^T dY."""

@@ -61,6 +61,25 @@ def test_driver_with_host_and_device_batch_builders():
         assert res["val"] > 0.3, (builder, res["val"])
 
 
+@pytest.mark.parametrize("model,extra", [
+    ("GCN2", {"alpha": 0.1, "theta": 0.5, "shared_weights": False}),
+    ("GraphSAGE", None),
+])
+def test_driver_with_neighbour_sampling_and_edge_dropout(model, extra):
+    """``num_neighbors`` and ``edge_dropout`` (loader.py:217-246, main.py:68) on the device
+    batch builder: batches are sampled on the GPU at every visit, their weights dropped at every
+    step, the steps are issued eagerly (nothing about such a batch is static), and the run
+    still learns the planted labels."""
+    from torch_geometric_autoscale import train, _lib
+    conf = _conf(model, False, dict(extra or {}), num_neighbors=8, batch_builder="device")
+    conf["model"]["params"]["arxiv"]["edge_dropout"] = 0.2
+    res = train.run(conf)
+    _lib.check_device_errors()
+    assert res["graphs"]["train_steps_recorded"] == 0
+    assert res["history"][-1]["loss"] < res["history"][0]["loss"]
+    assert res["val"] > 0.3, res["val"]
+
+
 @pytest.mark.parametrize("model,vr,extra,kind", [
     ("GCN2", True, {"alpha": 0.1, "theta": 0.5, "shared_weights": False, "dropout": 0.0}, "gcn2"),
     ("GCN2", False, {"alpha": 0.1, "theta": 0.5, "shared_weights": False, "dropout": 0.0}, "gcn2"),

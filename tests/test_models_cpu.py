@@ -26,3 +26,20 @@ def test_model_paths_on_cpu(name):
         mc.check_step_gradients(name, model, data, ptr, cpu, vr=True)
         mc.check_training_step(name, model, data, ptr, cpu, vr=False)
         mc.check_training_step(name, model, data, ptr, cpu, vr=True)
+
+
+@pytest.mark.parametrize("name", ["gcn2", "sage", "appnp", "gcn"])
+def test_sampled_and_edge_dropped_batches_on_cpu(name):
+    """A training step on a neighbour-sampled batch (loader.py:217-246) and on an edge-dropped
+    one (utils.py:62-73, main.py:68): host orchestration against the float64 step oracle."""
+    data, ptr, n_cls = mc.case_graph(name)
+    cpu = torch.device("cpu")
+    with cpu_kernels():
+        model = mc.make_model(name, data, data.x.size(1), n_cls, emb_device="cpu")
+        mc.check_refresh_sweep(name, model, data, ptr)
+        torch.manual_seed(11)
+        mc.check_step_gradients(name, model, data, ptr, cpu, vr=False, num_neighbors=4)
+        mc.check_step_gradients(name, model, data, ptr, cpu, vr=False, edge_dropout=0.3)
+        mc.check_step_gradients(name, model, data, ptr, cpu, vr=True, edge_dropout=0.3)
+        mc.check_step_gradients(name, model, data, ptr, cpu, vr=False, num_neighbors=6,
+                                edge_dropout=0.2)
