@@ -562,7 +562,11 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
   // (width >= 4.)  A row's last piece ends with the row: when the width is not a multiple of 4
   // its first `skip` floats are also the last floats of the neighbouring lane's piece -- both
   // lanes compute them from the same inputs in the same order, i.e. bit-identically.
-  const int coloff = live ? min(col0, a.width - 4) : 0;
+  // Lanes past the row's end (a last slice that the width does not fill) repeat the row's last
+  // piece: the same cache line as their live neighbours, result discarded.  (Pointing them at
+  // column 0 instead made the XCDs of a part-filled slice fetch a second line of every source
+  // row -- one that belongs to another slice's L2s.)
+  const int coloff = min(col0, a.width - 4);
   const int skip = live ? col0 - coloff : 0;
 
   if (vb < a.n_items) {
