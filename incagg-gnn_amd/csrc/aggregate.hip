@@ -425,14 +425,21 @@ __device__ __forceinline__ int group_bcast(int v) {
 // the row gathers.
 // WIDE: row offsets need 64 bits or the source is split in two matrices; otherwise a
 // 32-bit byte offset per lane on top of a scalar base is enough.
-template <bool INCAGG, int WIDE, bool ODD, int R0, int N>
+// BSEL >= 0 (lane groups of any size, see spmm_narrow_kernel): the indices come from lanes
+// bsel / 4 + R0 ... of the wave through ds_bpermute instead (`bsel`: byte address of the
+// group's first lane).
+template <bool INCAGG, int WIDE, bool ODD, int R0, int N, bool BPERM = false>
 __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float my_w, int coloff,
-                                              f4 &acc) {
+                                              f4 &acc, int bsel = 0) {
   int c[N];
   float w[N];
   f4 xv[N], mv[N];
 #pragma unroll
   for (int r = 0; r < N; r++) {
+    if constexpr (BPERM) {  // (the weights follow once the gathers are on their way)
+      c[r] = __builtin_amdgcn_ds_bpermute(bsel + 4 * (R0 + r), my_c);
+      continue;
+    }
     // (the ternary chain keeps the swizzle pattern an immediate)
     c[r] = r == 0 ? group_bcast<R0>(my_c) : r == 1 ? group_bcast<R0 + 1>(my_c)
          : r == 2 ? group_bcast<R0 + 2>(my_c) : r == 3 ? group_bcast<R0 + 3>(my_c)
@@ -472,6 +479,11 @@ __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float
       }
     }
   }
+  if constexpr (BPERM) {
+#pragma unroll
+    for (int r = 0; r < N; r++)
+      w[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bsel + 4 * (R0 + r), __float_as_int(my_w)));
+  }
   if (a.relu_x) {  // (kernel argument: a scalar branch, nothing on the other path)
 #pragma unroll
     for (int r = 0; r < N; r++)  // rows of the second source matrix are taken as they are
@@ -483,22 +495,22 @@ __device__ __forceinline__ void gather_rounds(const SpmmArgs &a, int my_c, float
 
 // `rounds` (wave-uniform, 1..8) rounds of the indices in (my_c, my_w): short windows only
 // pay for the rounds they fill: 1, 2, 4 or 8.
-template <bool INCAGG, int WIDE, bool ODD>
+template <bool INCAGG, int WIDE, bool ODD, bool BPERM = false>
 __device__ __forceinline__ void gather_some(const SpmmArgs &a, int my_c, float my_w, int rounds,
-                                            int coloff, f4 &acc) {
+                                            int coloff, f4 &acc, int bsel = 0) {
   if (rounds > 4) {
     if constexpr (INCAGG) {  // two operands per edge: 4 rounds = 8 gathers in flight
-      gather_rounds<INCAGG, WIDE, ODD, 0, 4>(a, my_c, my_w, coloff, acc);
-      gather_rounds<INCAGG, WIDE, ODD, 4, 4>(a, my_c, my_w, coloff, acc);
+      gather_rounds<INCAGG, WIDE, ODD, 0, 4, BPERM>(a, my_c, my_w, coloff, acc, bsel);
+      gather_rounds<INCAGG, WIDE, ODD, 4, 4, BPERM>(a, my_c, my_w, coloff, acc, bsel);
     } else {
-      gather_rounds<INCAGG, WIDE, ODD, 0, 8>(a, my_c, my_w, coloff, acc);
+      gather_rounds<INCAGG, WIDE, ODD, 0, 8, BPERM>(a, my_c, my_w, coloff, acc, bsel);
     }
   } else if (rounds > 2) {
-    gather_rounds<INCAGG, WIDE, ODD, 0, 4>(a, my_c, my_w, coloff, acc);
+    gather_rounds<INCAGG, WIDE, ODD, 0, 4, BPERM>(a, my_c, my_w, coloff, acc, bsel);
   } else if (rounds > 1) {
-    gather_rounds<INCAGG, WIDE, ODD, 0, 2>(a, my_c, my_w, coloff, acc);
+    gather_rounds<INCAGG, WIDE, ODD, 0, 2, BPERM>(a, my_c, my_w, coloff, acc, bsel);
   } else {
-    gather_rounds<INCAGG, WIDE, ODD, 0, 1>(a, my_c, my_w, coloff, acc);
+    gather_rounds<INCAGG, WIDE, ODD, 0, 1, BPERM>(a, my_c, my_w, coloff, acc, bsel);
   }
 }
 
@@ -721,6 +733,214 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock, INCAGG ? 4 : 8) void spmm_pl
   }
 }
 
+// ---------------------------------------------------------------- narrow rows in one pass
+// Rows of 33..64 floats (the 41- and 47-wide tables of APPNP: models/appnp.py:24) are more than
+// one 128-byte slice but much less than two: cut into slices, the second slice's XCDs walk the
+// whole edge list again for a few floats per row, and a row's cache lines are requested by two
+// L2s.  Here a group of L = ceil(width / 4) lanes (9..16) covers a WHOLE row with one 16-byte
+// piece per lane, so a load instruction of a wave fetches R = 64 / L different source rows and
+// the edge list is read once.  Same plan, same item / short-row split, same epilogue as
+// spmm_plan_kernel; the lane groups get their indices through ds_bpermute (a group no longer
+// is an aligned power of two of lanes).  The 64 - R L lanes left over shadow lanes of the last
+// group (same addresses, results discarded).
+struct NarrowLanes {
+  int g, t;       // lane group, piece within the row
+  bool live;      // owns a piece of an output row
+  int bsel;       // byte address (lane id * 4) of the group's first lane, for ds_bpermute
+};
+__device__ __forceinline__ NarrowLanes narrow_lanes(int lane, int L, int R) {
+  NarrowLanes n;
+  const bool spare = lane >= R * L;
+  n.g = spare ? R - 1 : lane / L;
+  n.t = spare ? lane - R * L : lane - n.g * L;
+  n.live = !spare;
+  n.bsel = n.g * L * 4;
+  return n;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+  v = max(v, __shfl_xor(v, 1));
+  v = max(v, __shfl_xor(v, 2));
+  v = max(v, __shfl_xor(v, 4));
+  v = max(v, __shfl_xor(v, 8));
+  v = max(v, __shfl_xor(v, 16));
+  v = max(v, __shfl_xor(v, 32));
+  return v;
+}
+
+template <int WIDE, bool ODD>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(
+    const SpmmArgs a, int L, int R, int groups) {
+  __shared__ f4 part[kWavesPerBlock][kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const NarrowLanes nl = narrow_lanes(lane, L, R);
+  const int g = nl.g, t = nl.t;
+  int vb = blockIdx.x;
+  if (groups > 1)
+    vb = vb < a.n_items ? regroup_ranges(vb, a.n_items, groups)
+                        : a.n_items + regroup(vb - a.n_items, (int)gridDim.x - a.n_items, groups,
+                                              a.n_items);
+  const int col0 = t * 4;                        // (< width: L = ceil(width / 4))
+  const int coloff = min(col0, a.width - 4);     // a row's last piece ends with the row
+  const int skip = col0 - coloff;
+
+  if (vb < a.n_items) {
+    // ---- one segment of a long row: wave w takes the windows w, w + 4, ... of 8 R edges; in a
+    // window lane (g, j < 8) holds edge j R + g, i.e. round j of group g
+    int row, seg_idx, es, ee, deg;
+    if (!item_range(a, vb, row, seg_idx, es, ee, deg)) return;  // block-uniform
+    const int win = 8 * R;
+    auto load_win = [&](int e0, int &c, float &w) {
+      const int slot = e0 + t * R + g;
+      const int e = min(slot, ee - 1);
+      if (a.edges) {
+        const int2 cw = a.edges[e];
+        c = cw.x;
+        w = __int_as_float(cw.y);
+      } else {
+        c = a.col[e];
+        w = a.val ? a.val[e] : 1.0f;
+      }
+      if (slot >= ee || t >= 8 || !nl.live) w = 0.f;
+      if ((unsigned)c >= (unsigned)a.n_cols) {  // never fault on a bad id
+        *a.err = 1;
+        c = 0;
+        w = 0.f;
+      }
+    };
+    f4 acc = f4(0.f);
+    int e0 = es + wave * win;
+    if (e0 < ee) {
+      int my_c, next_c = 0;
+      float my_w, next_w = 0.f;
+      load_win(e0, my_c, my_w);
+      for (; e0 < ee; e0 += win * kWavesPerBlock) {
+        const int ne0 = e0 + win * kWavesPerBlock;
+        if (ne0 < ee) load_win(ne0, next_c, next_w);
+        gather_some<false, WIDE, ODD, true>(a, my_c, my_w, (min(win, ee - e0) + R - 1) / R, coloff,
+                                            acc, nl.bsel);
+        my_c = next_c;
+        my_w = next_w;
+      }
+    }
+    part[wave][lane] = nl.live ? acc : f4(0.f);
+    __syncthreads();
+    if (wave != 0) return;
+    const bool multi = deg > a.seg;
+    int slot = -1;
+    if (multi && a.comb) {  // which of the plan's multi-segment rows this is (wave-uniform)
+      for (int base = 0; base < a.n_multi && slot < 0; base += kWave) {
+        const int idx = base + lane;
+        const unsigned long long hit = __ballot(idx < a.n_multi && a.multi_rows[idx] == row);
+        if (hit) slot = base + __ffsll((long long)hit) - 1;
+      }
+      if (slot < 0) {  // not in the list: reported, row left alone
+        *a.err = 1;
+        return;
+      }
+    }
+    if (g != 0 || !nl.live) return;
+    acc = f4(0.f);
+    for (int w = 0; w < kWavesPerBlock; w++)
+      for (int gg = 0; gg < R; gg++) acc += part[w][gg * L + t];
+    const float s = a.scale * (a.mean ? 1.0f / (float)max(deg, 1) : 1.0f);
+    f4 out = acc * s;
+    if (seg_idx == 0) {
+      if (a.add) out += a.add_scale * ld4<ODD>(a.add + (size_t)row * a.ldadd + coloff);
+      if (a.add2) out += a.add2_scale * ld4<ODD>(a.add2 + (size_t)row * a.ldadd2 + coloff);
+    }
+    if (a.gate) out = vgate<4>(out, ld4<ODD>(a.gate + (size_t)row * a.ldgate + coloff));
+    float *dst = a.y + (size_t)row * a.ldy + coloff;
+    if (!multi) {
+      st4<ODD>(dst, out);
+    } else if (a.comb) {
+      // (the protocol of spmm_plan_kernel's combine buffer, with one slice)
+      float *accp = a.comb + (size_t)slot * kCombineSlot + coloff;
+      const float r0 = atomicAdd(accp, skip > 0 ? 0.f : out.x);
+      const float r1 = atomicAdd(accp + 1, skip > 1 ? 0.f : out.y);
+      const float r2 = atomicAdd(accp + 2, skip > 2 ? 0.f : out.z);
+      const float r3 = atomicAdd(accp + 3, out.w);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
+      int *cnt = reinterpret_cast<int *>(a.comb + (size_t)slot * kCombineSlot + kCombineWidth);
+      // every piece counts its own arrival (one counter per piece: the pieces of a segment do
+      // not wait for each other)
+      const int prev = atomicAdd(cnt + t, 1);
+      if (prev == (deg + a.seg - 1) / a.seg - 1) {
+        if (skip < 1) dst[0] = atomicExch(accp, 0.f);
+        if (skip < 2) dst[1] = atomicExch(accp + 1, 0.f);
+        if (skip < 3) dst[2] = atomicExch(accp + 2, 0.f);
+        dst[3] = atomicExch(accp + 3, 0.f);
+        atomicExch(cnt + t, 0);
+      }
+    } else {  // several segments add onto the row, zeroed in front of this launch
+      if (skip < 1) atomicAdd(dst, out.x);
+      if (skip < 2) atomicAdd(dst + 1, out.y);
+      if (skip < 3) atomicAdd(dst + 2, out.z);
+      atomicAdd(dst + 3, out.w);
+    }
+    return;
+  }
+
+  // ---- short rows: a wave = R rows, every lane group owns one and walks its edges 8 at a time
+  const int p = a.n_hub + ((vb - a.n_items) * kWavesPerBlock + wave) * R + g;
+  const bool valid = nl.live && p < a.n_rows;
+  int row = 0, rs = 0, re = 0;
+  if (valid) {
+    row = a.order ? a.order[p] : p;
+    if ((unsigned)row >= (unsigned)a.n_rows) {  // bad plan entry: reported, not followed
+      *a.err = 1;
+      row = p;
+    }
+    row_range(a, row, rs, re);
+  }
+  const int deg = re - rs;
+  const int maxdeg = rfl(wave_max(deg));
+  auto load_idx = [&](int e0, int &c, float &w) {
+    if (e0 < re) {
+      const int slot = e0 + t;
+      const int e = min(slot, re - 1);
+      if (a.edges) {
+        const int2 cw = a.edges[e];
+        c = cw.x;
+        w = __int_as_float(cw.y);
+      } else {
+        c = a.col[e];
+        w = a.val ? a.val[e] : 1.0f;
+      }
+      if (slot >= re || t >= 8) w = 0.f;
+      if ((unsigned)c >= (unsigned)a.n_cols) {  // never fault on a bad id
+        *a.err = 1;
+        c = 0;
+        w = 0.f;
+      }
+    }
+  };
+  f4 acc = f4(0.f);
+  int e = rs;
+  int my_c = 0, next_c = 0;
+  float my_w = 0.f, next_w = 0.f;
+  load_idx(e, my_c, my_w);
+  for (int done = 0; done < maxdeg; done += 8) {
+    if (done + 8 < maxdeg) load_idx(e + 8, next_c, next_w);
+    // (rounds that SOME group still needs: wave-uniform.  A group whose row has ended sits the
+    // gathers out; the groups that go on only read indices from their own lanes.)
+    if (e < re)
+      gather_some<false, WIDE, ODD, true>(a, my_c, my_w, maxdeg - done, coloff, acc, nl.bsel);
+    my_c = next_c;
+    my_w = next_w;
+    e += 8;
+  }
+  if (valid) {
+    const float s = a.scale * (a.mean ? 1.0f / (float)max(deg, 1) : 1.0f);
+    f4 out = acc * s;
+    if (a.add) out += a.add_scale * ld4<ODD>(a.add + (size_t)row * a.ldadd + coloff);
+    if (a.add2) out += a.add2_scale * ld4<ODD>(a.add2 + (size_t)row * a.ldadd2 + coloff);
+    if (a.gate) out = vgate<4>(out, ld4<ODD>(a.gate + (size_t)row * a.ldgate + coloff));
+    st4<ODD>(a.y + (size_t)row * a.ldy + coloff, out);
+  }
+}
+
 // Rows that several items add onto start at zero: one wave per row.
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void zero_rows_kernel(
     const int *rows, int n, float *y, long long ldy, int width, int n_rows, int *err) {
@@ -772,6 +992,8 @@ struct Tuning {
   // matrices of more rows than plan_local_rows get a chunk-by-chunk row order (spmm_plan.hip)
   int plan_local_rows = env_int("INCAGG_PLAN_LOCAL_ROWS", 32768);
   int plan_chunk_rows = env_int("INCAGG_PLAN_CHUNK_ROWS", 1024);
+  // widest row the one-pass narrow kernel takes (rows wider than one 128-byte slice; 32 = off)
+  int narrow_max_width = env_int("INCAGG_NARROW_MAX_WIDTH", 48);
 };
 static Tuning &tuning() {
   static Tuning t;
@@ -872,6 +1094,28 @@ static int launch_sliced(SpmmArgs &a, const incagg_spmm_plan *plan, hipStream_t 
                       a.ldb2 < (1u << 24) && (long long)a.split * a.ldb1 < (1ll << 32) &&
                       rows2 * a.ldb2 < (1ll << 32);
   const bool odd = a.width % 4 != 0;
+  if constexpr (!INCAGG) {
+    // rows of 33..48 floats: whole rows per lane group, one pass over the edge list
+    if (a.width > kSliceFloats && a.width <= tuning().narrow_max_width) {
+      const int L = (a.width + 3) / 4, R = kWave / L;
+      const long long nblocks =
+          a.n_items + ((long long)(a.n_rows - a.n_hub) + kWavesPerBlock * R - 1) / (kWavesPerBlock * R);
+      INCAGG_REQUIRE(nblocks < INT_MAX, "grid too large");
+      const int ngroups = plan && plan_chunk_rows(a.n_rows) > 0 ? 8 : 1;
+      const dim3 ngrid((unsigned)nblocks);
+#define INCAGG_LAUNCH_NARROW(W, O) \
+  hipLaunchKernelGGL((spmm_narrow_kernel<W, O>), ngrid, block, 0, stream, a, L, R, ngroups)
+      if (fast24 && odd) INCAGG_LAUNCH_NARROW(2, true);
+      else if (fast24) INCAGG_LAUNCH_NARROW(2, false);
+      else if (wide && odd) INCAGG_LAUNCH_NARROW(1, true);
+      else if (wide) INCAGG_LAUNCH_NARROW(1, false);
+      else if (odd) INCAGG_LAUNCH_NARROW(0, true);
+      else INCAGG_LAUNCH_NARROW(0, false);
+#undef INCAGG_LAUNCH_NARROW
+      INCAGG_HIP_TRY(hipGetLastError());
+      return INCAGG_OK;
+    }
+  }
   // (a plan ordered chunk by chunk: see the kernel)
   const int groups = plan && plan_chunk_rows(a.n_rows) > 0 && (n_slices == 1 || n_slices == 2 || n_slices == 4)
                          ? 8 / n_slices : 1;
@@ -1026,6 +1270,7 @@ extern "C" int incagg_set_tuning(const char *key, int value) {
   else if (k == "wide_addressing") t.wide_addressing = value;
   else if (k == "plan_local_rows") t.plan_local_rows = value;
   else if (k == "plan_chunk_rows") t.plan_chunk_rows = value;
+  else if (k == "narrow_max_width") t.narrow_max_width = std::min(std::max(value, kSliceFloats), 64);
   else return fail(INCAGG_E_INVALID, "unknown tuning key '%s'", key);
   return INCAGG_OK;
 }

@@ -28,16 +28,21 @@ def ops():
 
 
 @pytest.fixture(params=["rows", "rows_plan", "sliced", "sliced_plan", "sliced_short_segments",
-                        "sliced_short_segments_zeroed", "rows_short_segments"])
+                        "sliced_short_segments_zeroed", "rows_short_segments",
+                        "two_slices_plan", "two_slices_short_segments"])
 def variant(request):
     """Forces one aggregation kernel (whole rows per wave / 128-byte feature slices) and one
     kind of work plan: none (rows in storage order, every row by one wave or lane group), the
     default plan (long rows as whole-workgroup items), or a plan with a low threshold and
-    128-edge segments, which sends many rows through the zero + atomic-combine path."""
+    128-edge segments, which sends many rows through the zero + atomic-combine path.
+    Rows of 33..48 floats on aligned pitches go to the one-pass narrow-row kernel in the
+    "sliced" variants and stay with the feature slices in the "two_slices" ones."""
     from torch_geometric_autoscale import _lib
     _lib.set_tuning("spmm_variant", 0 if request.param.startswith("rows") else 1)
+    _lib.set_tuning("narrow_max_width", 32 if request.param.startswith("two_slices") else 48)
     yield request.param
     _lib.set_tuning("spmm_variant", -1)
+    _lib.set_tuning("narrow_max_width", 48)
 
 
 def _plan(variant, rowptr32):
@@ -65,7 +70,7 @@ def _check(y_gpu, y64, y32=None):
         assert np.all(np.abs(y32 - y64) <= tol)
 
 
-WIDTHS = [256, 128, 100, 64, 41, 47, 4, 1, 3, 260, 512, 1024]
+WIDTHS = [256, 128, 100, 64, 41, 47, 36, 48, 4, 1, 3, 260, 512, 1024]
 
 
 @pytest.mark.parametrize("width", WIDTHS)
@@ -132,7 +137,7 @@ def _pitched(a, dev, pitch, fill=float("nan")):
     return buf, buf[:, :a.shape[1]]
 
 
-@pytest.mark.parametrize("width", [41, 47, 3, 6, 9, 33, 35, 129, 1023])
+@pytest.mark.parametrize("width", [41, 47, 3, 6, 9, 33, 35, 37, 40, 44, 45, 48, 129, 1023])
 def test_spmm_odd_widths_on_aligned_rows(ops, dev, width, variant):
     """Widths that are not a multiple of 4 on rows that start 16-byte aligned (the pitch the
     package allocates, ops.row_pitch): the feature-sliced kernel moves a row's last, partial
@@ -244,7 +249,7 @@ def test_spmm_hub_rows_sliced(ops, dev, variant):
     assert torch.allclose(y, y2, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("width", [256, 128, 36, 1024])
+@pytest.mark.parametrize("width", [256, 128, 36, 41, 48, 1024])
 def test_spmm_combine_buffer_is_left_clean(ops, dev, width):
     """Rows cut into several segments meet in the plan's combine buffer: many launches in a row
     over ONE plan (different widths use different parts of it) give the result of the zeroing
@@ -404,7 +409,7 @@ def test_chunked_plan_order(ops, dev, chunked_plans):
         assert np.all(first_short < chunk)          # chunk 0 leads the short rows
 
 
-@pytest.mark.parametrize("width", [8, 41, 64, 128, 256])
+@pytest.mark.parametrize("width", [8, 41, 47, 36, 64, 128, 256])
 def test_spmm_with_chunked_plan_matches_oracle(ops, dev, width, chunked_plans):
     """Narrow matrices under a chunk-ordered plan: the workgroups of an XCD walk one contiguous
     range of the plan (1, 2 and 4 slices; 8 slices as before)."""
