@@ -28,7 +28,7 @@ from torch import Tensor
 from .. import ops
 from ..aggregate import incagg_aggregate, spmm
 from ..history import History
-from ..nn import relu_into, unweighted
+from ..nn import PushTarget, relu_into, unweighted
 from ..pool import AsyncIOPool
 from ..sparse import SparseTensor
 
@@ -354,9 +354,23 @@ class ScalableGNN(torch.nn.Module):
         return all(h._base is not None and _same_device(h.emb.device, self.device)
                    for h in self.histories[1:])
 
+    def _push_target(self, history, like: Tensor, batch_size: Optional[int],
+                     offset: Optional[Tensor], count: Optional[Tensor]) -> Optional[PushTarget]:
+        """Where a layer's producer may store the (activated) output itself: the batch is ONE
+        range of rows of a table that lives where the model computes, and the push is an
+        ordinary local one (no staging pool)."""
+        if (batch_size is None or offset is None or count is None or self._async
+                or not like.is_cuda or not history.emb.is_cuda
+                or not _same_device(history.emb.device, like.device)):
+            return None
+        lo = self._batch_range(batch_size, offset, count)
+        if lo is None or lo + batch_size > history.emb.size(0):
+            return None
+        return PushTarget(history.emb, lo, relu=True)
+
     def _push_and_pull_split(self, history, x: Tensor, batch_size: Optional[int],
                              n_id: Optional[Tensor], offset: Optional[Tensor],
-                             count: Optional[Tensor], relu: bool = False
+                             count: Optional[Tensor], relu: bool = False, pushed: bool = False
                              ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
         """:meth:`push_and_pull` without the concatenation: returns the fresh in-batch rows
         and, separately, the out-of-batch rows (``None`` when there are none) plus, when
@@ -373,7 +387,8 @@ class ScalableGNN(torch.nn.Module):
         if self.partition_ctx is not None:
             # the local push; the out-of-batch rows were requested at the top of the step
             # (or are fetched now, when nothing was started: direct calls of this method)
-            history.push(x.detach(), n_id[:batch_size], self._local(offset), count, relu=relu)
+            if not pushed:
+                history.push(x.detach(), n_id[:batch_size], self._local(offset), count, relu=relu)
             plan = self._current_plan
             if plan is not None and self._in_place_ok(history, x):
                 if not getattr(self, "_halo_ready", False):
@@ -388,7 +403,8 @@ class ScalableGNN(torch.nn.Module):
                 return x, self._halo_pending.pop(0).wait(), None
             return x, (None if plan is None else plan.exchange(history.emb)), None
         if not self._async:
-            history.push(x.detach(), n_id[:batch_size], offset, count, relu=relu)
+            if not pushed:
+                history.push(x.detach(), n_id[:batch_size], offset, count, relu=relu)
             if n_id.numel() <= batch_size:
                 return x, None, None
             if self._in_place_ok(history, x):
@@ -533,14 +549,22 @@ class ScalableGNN(torch.nn.Module):
                 else:
                     agg = spmm(adj, x, reduce=self.agg_reduce, x_halo=halo, halo_ids=halo_ids,
                                **fuse)
+                    if i < self.num_layers - 1 and state['defer_relu']:
+                        state['push_into'] = self._push_target(self.histories[i + 1], agg,
+                                                               batch_size, offset, count)
                     h = self._update(i, agg, x, state)
                 self._release_halo()
+            offered = state.pop('push_into', None)
             if i < self.num_layers - 1:
                 if use_aggregation:
                     relu_pending = state.pop('relu_deferred', False)
+                    pushed = offered is not None and offered.done
+                    if pushed and not relu_pending:
+                        raise RuntimeError("a layer took the fused push without leaving its "
+                                           "activation to it")
                     x, halo, halo_ids = self._push_and_pull_split(
                         self.histories[i + 1], h, batch_size, nid, offset, count,
-                        relu=relu_pending)
+                        relu=relu_pending, pushed=pushed)
                 else:
                     x, _ = self.push_only(self.histories[i + 1], h, batch_size, nid, offset, count)
             else:
@@ -720,10 +744,21 @@ class ScalableGNN(torch.nn.Module):
             # later reader of these rows -- the next layer of the sweep, training steps --
             # reads them from the table)
             state['defer_relu'] = defer and i < last
+            if state['defer_relu'] and pool is None and count.numel() == 1 and use_aggregation:
+                hist = self.histories[i + 1]
+                if (agg.is_cuda and hist.emb.is_cuda and _same_device(hist.emb.device, agg.device)
+                        and int(offset[0]) + batch_size <= hist.emb.size(0)):
+                    state['push_into'] = PushTarget(hist.emb, int(offset[0]), relu=True)
             out = self._update(i, agg, x, state)[:batch_size]
+            offered = state.pop('push_into', None)
+            relu = state.pop('relu_deferred', False)
+            if offered is not None and offered.done:
+                if not relu:
+                    raise RuntimeError("a layer took the fused push without leaving its "
+                                       "activation to it")
+                return
             target = self._out if i == last else self.histories[i + 1].emb
-            self._push_rows(target, out, offset, count, pool,
-                            relu=state.pop('relu_deferred', False))
+            self._push_rows(target, out, offset, count, pool, relu=relu)
 
         for data, batch_size, n_id, offset, count, state in batches:
             if batch_size == 0:      # padding batch of a partition-parallel run

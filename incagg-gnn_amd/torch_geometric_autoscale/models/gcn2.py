@@ -106,9 +106,16 @@ class GCN2(ScalableGNN):
     def _update(self, layer: int, agg: Tensor, x: Tensor, state: Dict[str, Any],
                 pre: bool = False) -> Tensor:
         if 'x0_terms' in state:
+            # (the push of this layer's output may ride with its GEMM when nothing stands between
+            # the GEMM and the push: no batch norm, no residual, the activation left to the push)
+            push = state.get('push_into')
+            if push is not None and (self.batch_norm or self.residual
+                                     or not state.get('defer_relu')
+                                     or layer >= self.num_layers - 1):
+                push = None
             h = self.convs[layer].forward_after_propagate(
                 agg, state['x_0'], state['w1f'][layer], state['x0_terms'][layer],
-                None if state.get('dw1') is None else state['dw1'][layer])
+                None if state.get('dw1') is None else state['dw1'][layer], push)
         else:
             h = self.convs[layer].forward_after_propagate(agg, state['x_0'])
         return self._post(layer, h, x, state)

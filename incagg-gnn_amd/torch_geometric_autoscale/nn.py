@@ -237,19 +237,50 @@ def embed_relu(lin: Linear, x: Tensor, n_batch: int, grad_gated: bool = False):
     return _EmbedRelu.apply(x, lin.weight, lin.bias, n_batch, grad_gated)
 
 
+class PushTarget:
+    """Where the History push of a layer's output goes when the kernel that PRODUCES the output
+    does it: rows ``[row0, row0 + rows)`` of ``table`` receive the output (``relu``:
+    ``max(0, output)``).  ``done`` is set by the producer that took the offer; otherwise the
+    caller pushes as usual."""
+
+    def __init__(self, table: Tensor, row0: int, relu: bool):
+        self.table, self.row0, self.relu, self.done = table, int(row0), bool(relu), False
+
+    def fits(self, rows: int, width: int, like: Tensor) -> bool:
+        t = self.table
+        return (t.is_cuda and t.device == like.device and t.dtype == torch.float32
+                and t.size(1) == width and 0 <= self.row0 and self.row0 + rows <= t.size(0))
+
+
+def fused_layer_kernel_enabled() -> bool:
+    """``INCAGG_FUSED_LAYER=0`` keeps the dense update with hipBLASLt and the push as a copy."""
+    import os
+    return os.environ.get("INCAGG_FUSED_LAYER", "1") != "0"
+
+
 class _TwoTermUpdate(torch.autograd.Function):
     """``h @ W1 + x0 @ W2`` (``x0`` / ``W2`` optional) with split-row weight gradients.
     ``term``: the second summand ready-made; the product is then accumulated INTO it (the GEMM
     reads and writes the same matrix: no copy of the summand in front of it) and it is the
-    result."""
+    result.  ``push``: a :class:`PushTarget` -- with a ready-made summand the whole update then
+    runs as ONE hand-written matrix-core launch (ops.rows_gemm) that also stores the result,
+    activated, into the next layer's table."""
 
     @staticmethod
-    def forward(ctx, h, w1, x0, w2, term=None, dw1_out=None):
+    def forward(ctx, h, w1, x0, w2, term=None, dw1_out=None, push=None):
         ctx.save_for_backward(h, w1, x0, w2)
         ctx.has_term = term is not None
         ctx.dw1_out = dw1_out       # where the caller wants the gradient of w1 (may be ignored)
         if term is not None:
             ctx.mark_dirty(term)
+            if (push is not None and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
+                    and h.stride(1) == 1 and w1.stride(1) == 1 and term.stride(1) == 1
+                    and ops.rows_gemm_supported(h.size(1), w1.size(1))
+                    and push.fits(h.size(0), w1.size(1), h) and fused_layer_kernel_enabled()):
+                ops.rows_gemm(h, w1, False, out=term, accumulate=True, table=push.table,
+                              table_row0=push.row0, relu_push=push.relu)
+                push.done = True
+                return term
             return term.addmm_(h, w1)
         if x0 is None:
             return _mm_rows(h, w1)
@@ -267,7 +298,7 @@ class _TwoTermUpdate(torch.autograd.Function):
             dx0 = dy @ w2.t() if ctx.needs_input_grad[2] else None
             dw2 = _tn_product(x0, dy) if ctx.needs_input_grad[3] else None
         dterm = dy if ctx.has_term and ctx.needs_input_grad[4] else None
-        return dh, dw1, dx0, dw2, dterm, None
+        return dh, dw1, dx0, dw2, dterm, None, None
 
 
 class _Layers(torch.autograd.Function):
@@ -562,13 +593,14 @@ class GCN2Conv(torch.nn.Module):
 
     def forward_after_propagate(self, h: Tensor, x_0: Tensor, w1_folded: Optional[Tensor] = None,
                                 x0_term: Optional[Tensor] = None,
-                                dw1_out: Optional[Tensor] = None) -> Tensor:
+                                dw1_out: Optional[Tensor] = None,
+                                push: Optional[PushTarget] = None) -> Tensor:
         """Everything after the propagation, given ``h = A x`` (models/gcn2.py:257,306).
         ``w1_folded`` / ``x0_term``: this layer's slice of :func:`gcn2_batched_terms`, computed
-        for all layers at once by the caller."""
+        for all layers at once by the caller.  ``push``: see :class:`PushTarget`."""
         b = h.size(0)
         if x0_term is not None:
-            return _TwoTermUpdate.apply(h, w1_folded, None, None, x0_term, dw1_out)
+            return _TwoTermUpdate.apply(h, w1_folded, None, None, x0_term, dw1_out, push)
         x_0 = x_0 if x_0.size(0) == b else x_0[:b]
         if self.weight2 is None:
             p = torch.add(h * (1 - self.alpha), x_0, alpha=self.alpha)

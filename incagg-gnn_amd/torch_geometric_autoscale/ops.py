@@ -432,6 +432,50 @@ def tn_finish_batched(parts, tails, out: Tensor) -> Tensor:
     return out
 
 
+def rows_gemm_supported(k: int, n: int) -> bool:
+    """Whether :func:`rows_gemm` takes a ``[rows, k] x [k, n]`` product."""
+    return bool(lib().incagg_rows_gemm_supported(int(k), int(n)))
+
+
+def rows_gemm(x: Tensor, w: Tensor, trans_w: bool = False, out: Optional[Tensor] = None,
+              accumulate: bool = False, table: Optional[Tensor] = None, table_row0: int = 0,
+              relu_push: bool = False) -> Tensor:
+    """``out = (out if accumulate else 0) + x @ w`` (``trans_w``: ``x @ w.T``) for a tall ``x``
+    ``[rows, k]`` and a small weight, on the matrix cores in exact fp32
+    (incagg_rows_gemm_f32); ``table``: rows ``[table_row0, table_row0 + rows)`` of it receive
+    the result too (``relu_push``: ``max(0, result)``) -- the History push of a layer's output,
+    done by the producer.  ``out`` defaults to a fresh matrix at the gather pitch."""
+    _need_cuda(x, "x")
+    _rows_f32(x, "x")
+    if w.dim() != 2 or w.dtype != torch.float32 or w.device != x.device or w.stride(1) != 1:
+        raise ValueError("w must be an fp32 matrix with unit column stride on the device of x")
+    k = x.size(1)
+    n = w.size(0) if trans_w else w.size(1)
+    if (w.size(1) if trans_w else w.size(0)) != k:
+        raise ValueError(f"shapes do not match: x is {tuple(x.shape)}, w {tuple(w.shape)}"
+                         f"{' (transposed)' if trans_w else ''}")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an out matrix")
+        out = rows_empty(x.size(0), n, x.device)
+    else:
+        _rows_f32(out, "out", x.device)
+        if out.size(0) != x.size(0) or out.size(1) != n:
+            raise ValueError("out has the wrong shape")
+    t_ptr = t_ld = t_rows = 0
+    if table is not None:
+        _rows_f32(table, "table", x.device)
+        if table.size(1) < n:
+            raise ValueError("table rows are narrower than the result")
+        t_ptr, t_ld, t_rows = table.data_ptr(), _ld(table), table.size(0)
+    with _on_device(x.device):
+        check(lib().incagg_rows_gemm_f32(
+            _ptr(x), _ld(x), _ptr(w), w.stride(0), 1 if trans_w else 0, x.size(0), k, n,
+            1 if accumulate else 0, _ptr(out), _ld(out), t_ptr or None, t_ld, t_rows,
+            int(table_row0), 1 if relu_push else 0, _stream_of(x.device)))
+    return out
+
+
 def relu_rows_(x: Tensor) -> Tensor:
     """``x.relu_()`` over a [rows, width] matrix at streaming rate (incagg_relu_rows_f32).
     Outside autograd."""

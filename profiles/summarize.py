@@ -33,7 +33,7 @@ def main():
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
     # (the spin kernel that bench.py puts in front of its event-timed eager pass is no step work)
     rows = [r for r in rows if 'spin_kernel' not in r['Kernel_Name']]
-    main_kernels = ('spmm_rows_kernel', 'spmm_plan_kernel')
+    main_kernels = ('spmm_rows_kernel', 'spmm_plan_kernel', 'spmm_narrow_kernel')
     idx = [i for i, r in enumerate(rows) if any(k in r['Kernel_Name'] for k in main_kernels)]
     first = idx[-(steps + skip) * per_step_aggs]
     last = idx[-skip * per_step_aggs] if skip else len(rows)

@@ -1,17 +1,26 @@
-"""From a rocprofv3 kernel trace of `bench.py --sweep on`: GPU busy time, span and kernel mix of
-the refresh sweep (everything after the last optimizer kernel).  argv[1]: trace directory."""
+"""From a rocprofv3 kernel trace of `bench.py --sweep on --steps 2 --warmup 1 --no-cpu-baseline
+--epoch-pass off`: GPU busy time, span and kernel mix of the LAST refresh sweep of the run (the
+timed replay; bench.py issues it after its steps).  A sweep is recognised by its aggregation
+launches that come in a row without an optimizer kernel in between.  argv[1]: trace directory."""
 import collections
 import csv
 import glob
 import re
 import sys
 
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-last = max(i for i, n in enumerate(names) if "FusedOptimizer" in n or "adam_bump_kernel" in n)
-sw = rows[last + 1:]
+opt = [i for i, n in enumerate(names) if "adam_bump_kernel" in n or "FusedOptimizer" in n]
+# the last stretch without optimizer kernels that holds more than 100 aggregation launches
+cuts = [-1] + opt + [len(rows)]
+best = None
+for a, b in zip(cuts[:-1], cuts[1:]):
+    seg = rows[a + 1:b]
+    if sum("spmm_" in r["Kernel_Name"] for r in seg) > 100:
+        best = seg
+sw = best
 dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 print("sweep kernels", len(sw), "busy ms", sum(map(dur, sw)) / 1e6, "span ms",
       (int(sw[-1]["End_Timestamp"]) - int(sw[0]["Start_Timestamp"])) / 1e6)

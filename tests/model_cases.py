@@ -352,8 +352,11 @@ def check_deferred_activation(device, vr, kind="gcn2"):
             continue
         o2, t2, g2 = results[(key[0], False, key[2])]
         assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-6), key
+        # (equal up to the summation order of the dense update: with the activation deferred
+        # the update and the push of a single-range batch are one hand-written launch, without
+        # it a library GEMM and a copy)
         for a, b_ in zip(t1, t2):
-            assert torch.equal(a, b_), key
+            assert torch.allclose(a, b_, rtol=1e-5, atol=1e-6), key
         assert g1.keys() == g2.keys() and len(g1) >= (6 if kind == "gcn2" else 5)
         for k in g1:
             assert torch.allclose(g1[k], g2[k], rtol=1e-4, atol=1e-6), (key, k)

@@ -213,3 +213,48 @@ def test_rows_sum_matches_torch(ops, dev, rows, width, n):
         ops.rows_sum([])
     with pytest.raises(ValueError):
         ops.rows_sum(srcs + [srcs[0][:, :max(width - 1, 0)]])
+
+
+@pytest.mark.parametrize("rows,k,n", [(16326, 256, 256), (1000, 64, 128), (130, 32, 100), (64, 256, 4),
+                                      (5, 96, 256), (4097, 128, 36)])
+@pytest.mark.parametrize("trans_w", [False, True])
+def test_rows_gemm_matches_float64(rows, k, n, trans_w):
+    """The hand-written fp32 matrix-core product against a float64 product of the same fp32
+    operands: plain, accumulating into a column block of a wider matrix, and with the fused
+    History push (with and without the activation) into a range of table rows -- everything
+    outside the addressed rows / columns untouched."""
+    from torch_geometric_autoscale import ops, _lib
+    dev = torch.device("cuda", 0)
+    assert ops.rows_gemm_supported(k, n)
+    g = torch.Generator(device="cpu").manual_seed(rows + k + n)
+    xbuf = torch.randn(rows, k + 8, generator=g).to(dev)
+    x = xbuf[:, :k]
+    w = torch.randn((n, k) if trans_w else (k, n), generator=g).to(dev) * 0.1
+    ref = x.double() @ (w.double().t() if trans_w else w.double())
+    scale = float(ref.abs().max())
+    tol = 2e-6 * scale * (k ** 0.5)
+    y = ops.rows_gemm(x, w, trans_w)
+    assert y.shape == (rows, n) and float((y.double() - ref).abs().max()) <= tol
+    assert torch.allclose(y, x @ (w.t() if trans_w else w), rtol=1e-4, atol=1e-4 * scale)
+    # accumulate into a block of a wider matrix + push max(0, .) into table rows [7, 7 + rows)
+    wide = torch.randn(rows, 3 * n + 4, generator=g).to(dev)
+    before = wide.clone()
+    blk = wide[:, n:2 * n]
+    table = torch.full((rows + 20, n + 12), 3.0, device=dev)
+    out = ops.rows_gemm(x, w, trans_w, out=blk, accumulate=True, table=table, table_row0=7,
+                        relu_push=True)
+    assert out.data_ptr() == blk.data_ptr()
+    want = before[:, n:2 * n].double() + ref
+    assert float((blk.double() - want).abs().max()) <= tol + 1e-6 * float(want.abs().max())
+    assert torch.equal(wide[:, :n], before[:, :n]) and torch.equal(wide[:, 2 * n:], before[:, 2 * n:])
+    assert torch.equal(table[7:7 + rows, :n], torch.relu(blk))
+    assert bool((table[:7] == 3.0).all()) and bool((table[7 + rows:] == 3.0).all())
+    assert bool((table[:, n:] == 3.0).all())
+    table.fill_(3.0)
+    ops.rows_gemm(x, w, trans_w, out=blk, table=table, table_row0=0)
+    assert torch.equal(table[:rows, :n], blk)
+    with pytest.raises(Exception):
+        ops.rows_gemm(x, w, trans_w, out=blk, table=table, table_row0=21)
+    with pytest.raises(Exception):
+        ops.rows_gemm(xbuf[:, :k - 1], w[:, :k - 1] if trans_w else w[:k - 1], trans_w)
+    _lib.check_device_errors()
