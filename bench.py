@@ -359,6 +359,7 @@ def main():
     if sharded:
         if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        __import__('torch_geometric_autoscale').distributed.enable_collective_records()
         dist.init_process_group("nccl", device_id=dev)
 
     import torch_geometric_autoscale as tga

@@ -295,15 +295,51 @@ def allreduce_gradients(module: torch.nn.Module, ctx: PartitionContext) -> None:
         off += n
 
 
-def quiesce_collectives(seconds: float = 1.5) -> None:
-    """Waits until every collective issued so far has completed AND the process group's
-    watchdog thread has retired its bookkeeping for them (it polls their events a few times per
-    second, and an event poll while a stream records a HIP graph is an error on some builds):
-    call it between the last eager collective and a graph recording."""
+def enable_collective_records(entries: int = 2000) -> None:
+    """Turns on torch.distributed's record of issued collectives (its "flight recorder"), which
+    :func:`quiesce_collectives` reads.  Call BEFORE ``init_process_group``; an explicit setting in
+    the environment is left alone."""
+    import os
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", str(int(entries)))
+
+
+def quiesce_collectives(timeout: float = 10.0) -> str:
+    """Returns once every collective issued so far has completed AND the process group's
+    watchdog thread has retired its bookkeeping for it (the thread polls the collectives'
+    events a few times per second, and an event poll while a stream records a HIP graph is an
+    error on some builds): call it between the last eager collective and a graph recording.
+
+    The condition is read from torch.distributed's record of collectives (every entry marked
+    ``retired``; :func:`enable_collective_records`) -- returns ``"retired"``.  Where that record
+    is not kept, the call falls back to waiting 1.5 s, fifteen polling periods of the watchdog,
+    and returns ``"slept"``."""
+    import pickle
     import time
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    time.sleep(seconds)
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace
+    except ImportError:
+        _dump_nccl_trace = None
+    if _dump_nccl_trace is not None and dist.is_initialized():
+        deadline = time.monotonic() + timeout
+        while True:
+            try:
+                # (a dict of plain values written by this process's own torch)
+                entries = pickle.loads(_dump_nccl_trace()).get("entries", [])
+            except Exception:
+                break
+            if not entries:
+                break                       # no record is kept (or nothing was ever issued)
+            if all(e.get("retired", False) for e in entries):
+                return "retired"
+            if time.monotonic() > deadline:
+                raise RuntimeError(f"collectives still pending after {timeout} s: "
+                                   f"{sum(not e.get('retired', False) for e in entries)} of "
+                                   f"{len(entries)} records not retired")
+            time.sleep(0.005)
+    time.sleep(1.5)
+    return "slept"
 
 
 def flatten_gradients(module: torch.nn.Module) -> Tensor:

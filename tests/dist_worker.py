@@ -31,6 +31,8 @@ def main():
     if on_gpu:
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(dev)
+        from torch_geometric_autoscale import distributed as D
+        D.enable_collective_records()
         dist.init_process_group("nccl", device_id=dev)
     else:
         dev = torch.device("cpu")

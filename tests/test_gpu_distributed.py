@@ -27,6 +27,8 @@ def rccl():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    from torch_geometric_autoscale import distributed as D
+    D.enable_collective_records()
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=dev)
     yield dev
@@ -175,7 +177,9 @@ def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
     graphs = StepGraphs(dev)
     for k in range(len(subs)):                  # lazily built per-batch structures, then record
         graphs.warm(lambda: step(k, replay=False), times=1)
-    D.quiesce_collectives()
+    # (a condition, not a pause: every collective issued so far is marked retired in
+    # torch.distributed's own record before the recording starts)
+    assert D.quiesce_collectives() == "retired"
     for k in range(len(subs)):
         graphs.capture(k, lambda: body(k), capture_error_mode="thread_local")
     torch.cuda.synchronize()
