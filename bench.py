@@ -798,7 +798,8 @@ def main():
             line["roofline"] = {
                 "bound": "hbm", "achieved": ks["algo_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ks["algo_GBps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(args),
-                "kernel": "spmm_plan_kernel, forward and transposed launches (one launch per call)",
+                "kernel": ("spmm_narrow_kernel" if 32 < model.histories[-1].embedding_dim <= 48 else "spmm_plan_kernel")
+                + ", forward and transposed launches (one launch per call)",
                 "avg_launch_ms": ks["avg_ms"], "launches": ks["launches"],
                 "algorithmic_bytes_per_launch": ks["algo_bytes_per_launch"],
                 "gather_bound_GBps": ks["gather_GBps"],

@@ -7,7 +7,7 @@ import glob
 import json
 import sys
 
-MAIN = ("spmm_rows_kernel", "spmm_plan_kernel")
+MAIN = ("spmm_rows_kernel", "spmm_plan_kernel", "spmm_narrow_kernel")
 
 
 def main():

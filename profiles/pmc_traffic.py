@@ -18,7 +18,7 @@ import sys
 KERNEL_SOURCE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                              "incagg-gnn_amd", "csrc", "aggregate.hip")
 
-MAIN = ("spmm_rows_kernel", "spmm_plan_kernel")
+MAIN = ("spmm_rows_kernel", "spmm_plan_kernel", "spmm_narrow_kernel")
 SECOND = ("zero_rows_kernel",)
 
 
