@@ -85,6 +85,12 @@ def test_driver_with_neighbour_sampling_and_edge_dropout(model, extra):
     ("GCN2", False, {"alpha": 0.1, "theta": 0.5, "shared_weights": False, "dropout": 0.0}, "gcn2"),
     ("GCN", True, {"dropout": 0.0}, "gcn"),
     ("GraphSAGE", False, {"dropout": 0.0}, "sage"),
+    # the headline architecture: 8 layers x 256, a weight pair per layer (fused layer kernel,
+    # wide x_0 GEMM, 8-slab weight gradients), both step kinds
+    ("GCN2", False, {"alpha": 0.1, "theta": 0.5, "shared_weights": False, "dropout": 0.0,
+                     "num_layers": 8, "hidden_channels": 256}, "gcn2"),
+    ("GCN2", True, {"alpha": 0.1, "theta": 0.5, "shared_weights": False, "dropout": 0.0,
+                    "num_layers": 8, "hidden_channels": 256}, "gcn2"),
 ])
 def test_driver_ends_with_exact_tables_and_outputs(model, vr, extra, kind):
     """After the driver's last refresh the tables hold the full-graph layer inputs (and, in the
