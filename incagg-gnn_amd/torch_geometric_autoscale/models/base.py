@@ -760,13 +760,23 @@ class ScalableGNN(torch.nn.Module):
             target = self._out if i == last else self.histories[i + 1].emb
             self._push_rows(target, out, offset, count, pool, relu=relu)
 
+        # Models that embed their features row by row in front of layer 0 (GCNII, APPNP): with
+        # the tables in HBM every batch embeds only its OWN rows and stores them in
+        # ``histories[0]``; layer 0 then aggregates like every other layer, its out-of-batch
+        # rows read in place from that table -- instead of embedding the M >> B rows of every
+        # batch's neighbourhood over again (the union of the batches covers every node once; the
+        # values are the same either way).
+        embed_once = (in_place and not sharded and use_aggregation and not self.raw_input_layer
+                      and self.device.type == 'cuda'
+                      and all(b[1] > 0 for b in batches))
         for data, batch_size, n_id, offset, count, state in batches:
             if batch_size == 0:      # padding batch of a partition-parallel run
                 continue
             adj_t = data.adj_t.to(self.device)
             state['keep_layer_terms'] = keep_terms
-            x = self._embed(_features_on(data, self.device), state, batch_size)
-            if with_aggregates:
+            feats = _features_on(data, self.device)
+            x = self._embed(feats[:batch_size] if embed_once else feats, state, batch_size)
+            if with_aggregates or embed_once:
                 if x.size(1) > self.histories[0].embedding_dim:
                     raise ValueError(
                         f"layer-0 rows are {x.size(1)} wide but the History tables only "
@@ -774,12 +784,13 @@ class ScalableGNN(torch.nn.Module):
                         "(device=...) or choose hidden_channels >= in_channels")
                 self._push_rows(self.histories[0].emb, x[:batch_size], self._local(offset), count,
                                 pool)
-            run_layer(0, x, adj_t, batch_size, offset, count, state)
+            if not embed_once:
+                run_layer(0, x, adj_t, batch_size, offset, count, state)
         if use_pool:
             pool.synchronize_push()
             pool_ag.synchronize_push()
 
-        for i in range(1, self.num_layers):
+        for i in range(0 if embed_once else 1, self.num_layers):
             if use_pool:  # prime the queue for the whole layer (models/gcn.py:378-379)
                 for _, batch_size, n_id, offset, count, _ in batches:
                     pool.async_pull(self.histories[i].emb, offset, count, n_id[batch_size:])
