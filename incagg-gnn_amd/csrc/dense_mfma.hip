@@ -1,6 +1,6 @@
 // Dense update of a layer on the matrix cores of gfx950, in exact fp32:
 //
-//     Y[rows, N] = (accumulate ? Y : 0) + X[rows, K] @ W          (W: [K, N], or W^T: [N, K])
+//     Y[rows, N] = (accumulate ? Y : 0) + bias[N] + X[rows, K] @ W   (W: [K, N], or W^T: [N, K])
 //     table[table_row0 + i, :N] = Y[i, :]  (optionally max(0, .))   -- the History push, fused
 //
 // i.e. what follows the aggregation in a GCNII / GCN / GraphSAGE layer (models/gcn2.py:257,306:
@@ -46,6 +46,7 @@ struct GemmArgs {
   long long ldx;
   const float *w;      // TRANS_W: [N, K] (row pitch ldw), else [K, N]
   long long ldw;
+  const float *bias;   // optional, [N]: added once (on top of the accumulated-into y, if any)
   float *y;
   long long ldy;
   float *table;        // optional: rows [table_row0, table_row0 + rows) receive Y (or max(0, Y))
@@ -111,19 +112,21 @@ __global__ __launch_bounds__(kGemmThreads) void rows_gemm_kernel(const GemmArgs 
   f16v acc[2];
   auto tile_row = [&](int r) { return row0 + wrow + 8 * (r >> 2) + 4 * half + (r & 3); };
   const bool full = row0 + kTileRows <= g.rows && wcol + 64 <= g.n;   // (wave-uniform)
+#pragma unroll
+  for (int cb = 0; cb < 2; cb++) {
+    const int col = min(wcol + 32 * cb + l32, g.n - 1);
+    const float b = g.bias && wave_live ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[cb][r] = b;
+  }
   if (g.accumulate && wave_live) {
 #pragma unroll
     for (int cb = 0; cb < 2; cb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = min(tile_row(r), g.rows - 1), col = min(wcol + 32 * cb + l32, g.n - 1);
-        acc[cb][r] = g.y[(long long)row * g.ldy + col];
+        acc[cb][r] += g.y[(long long)row * g.ldy + col];
       }
-  } else {
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
   }
 
   store_chunk(0);
@@ -212,8 +215,8 @@ extern "C" int incagg_rows_gemm_supported(int64_t k, int64_t n) {
 }
 
 extern "C" int incagg_rows_gemm_f32(const float *x, int64_t ldx, const float *w, int64_t ldw,
-                                    int trans_w, int64_t rows, int64_t k, int64_t n,
-                                    int accumulate, float *y, int64_t ldy, float *table,
+                                    int trans_w, const float *bias, int64_t rows, int64_t k,
+                                    int64_t n, int accumulate, float *y, int64_t ldy, float *table,
                                     int64_t ldt, int64_t table_rows, int64_t table_row0,
                                     int relu_push, void *stream) {
   INCAGG_REQUIRE(rows >= 0 && rows < INT_MAX - kTileRows, "rows %lld out of range", (long long)rows);
@@ -234,7 +237,7 @@ extern "C" int incagg_rows_gemm_f32(const float *x, int64_t ldx, const float *w,
                    "the table must not alias x or y");
   }
   GemmArgs g{};
-  g.x = x; g.ldx = ldx; g.w = w; g.ldw = ldw; g.y = y; g.ldy = ldy;
+  g.x = x; g.ldx = ldx; g.w = w; g.ldw = ldw; g.bias = bias; g.y = y; g.ldy = ldy;
   g.table = table; g.ldt = ldt; g.table_row0 = table_row0;
   g.rows = (int)rows; g.k = (int)k; g.n = (int)n;
   g.accumulate = accumulate != 0; g.relu_push = relu_push != 0;

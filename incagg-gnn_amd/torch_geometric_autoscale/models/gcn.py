@@ -88,15 +88,22 @@ class GCN(ScalableGNN):
     def _pre_aggregate(self, layer: int, x: Tensor) -> Optional[Tensor]:
         return self.convs[layer].lin(x) if self._pre_aggregates(layer) else None
 
-    def _conv_update(self, layer: int, agg: Tensor, x: Tensor, pre: bool) -> Tensor:
+    def _conv_update(self, layer: int, agg: Tensor, x: Tensor, pre: bool, push=None) -> Tensor:
         conv = self.convs[layer]
         if pre:
             return agg if conv.bias is None else agg + conv.bias
-        return conv.update(agg)
+        return conv.update(agg, push)
 
     def _update(self, layer: int, agg: Tensor, x: Tensor, state: Dict[str, Any],
                 pre: bool = False) -> Tensor:
-        h = self._conv_update(layer, agg, x, pre)
+        # (the push of this layer's output may ride with its GEMM when nothing stands between
+        # the two: no batch norm, no residual, the activation left to the push)
+        push = state.get('push_into')
+        if push is not None and (self.batch_norm or self.residual or self.linear
+                                 or not state.get('defer_relu')
+                                 or layer >= self.num_layers - 1):
+            push = None
+        h = self._conv_update(layer, agg, x, pre, push)
         if layer < self.num_layers - 1 or self.linear:
             if self.batch_norm:
                 h = self.bns[layer](h)

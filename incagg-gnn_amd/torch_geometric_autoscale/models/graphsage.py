@@ -20,5 +20,5 @@ class GraphSAGE(GCN):
     def _pre_aggregate(self, layer: int, x: Tensor) -> Optional[Tensor]:
         return None  # lin_l follows the mean; the root term needs the untouched input
 
-    def _conv_update(self, layer: int, agg: Tensor, x: Tensor, pre: bool) -> Tensor:
+    def _conv_update(self, layer: int, agg: Tensor, x: Tensor, pre: bool, push=None) -> Tensor:
         return self.convs[layer].update(agg, x)

@@ -158,9 +158,18 @@ class _RowsLinear(torch.autograd.Function):
     """``x @ W^T + b`` over node rows with the weight gradient evaluated by :func:`_tn_product`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gathered=True):
+    def forward(ctx, x, weight, bias, gathered=True, push=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if (push is not None and gathered and x.is_cuda and x.dim() == 2
+                and x.dtype == torch.float32 and x.stride(1) == 1 and weight.stride(1) == 1
+                and ops.rows_gemm_supported(x.size(1), weight.size(0))
+                and push.fits(x.size(0), weight.size(0), x) and fused_layer_kernel_enabled()):
+            # product, bias and the (activated) push of the result in one matrix-core launch
+            out = ops.rows_gemm(x, weight, True, bias=bias, table=push.table,
+                                table_row0=push.row0, relu_push=push.relu)
+            push.done = True
+            return out
         if not gathered:    # plain contiguous result (bias in the GEMM's epilogue)
             return x @ weight.t() if bias is None else torch.addmm(bias, x, weight.t())
         if bias is None:
@@ -177,7 +186,7 @@ class _RowsLinear(torch.autograd.Function):
         dx = _mm_rows(dy, weight) if ctx.needs_input_grad[0] else None
         dw = _tn_product(dy, x) if ctx.needs_input_grad[1] else None
         db = _column_sums(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _EmbedRelu(torch.autograd.Function):
@@ -519,13 +528,14 @@ class GCNConv(torch.nn.Module):
         if self.bias is not None:
             torch.nn.init.zeros_(self.bias)
 
-    def update(self, agg: Tensor) -> Tensor:
-        """Dense part applied to an aggregate of the layer INPUT (models/gcn.py:242-244)."""
+    def update(self, agg: Tensor, push: Optional["PushTarget"] = None) -> Tensor:
+        """Dense part applied to an aggregate of the layer INPUT (models/gcn.py:242-244).
+        ``push``: see :class:`PushTarget`."""
         if self.bias is None or agg.dim() != 2 or not agg.is_cuda:
             h = self.lin(agg)
             return h if self.bias is None else h + self.bias
         # bias in the GEMM's epilogue, its gradient as streaming column sums
-        return _RowsLinear.apply(agg, self.lin.weight, self.bias, True)
+        return _RowsLinear.apply(agg, self.lin.weight, self.bias, True, push)
 
     def forward(self, x: Tensor, adj_t: SparseTensor) -> Tensor:
         if self.in_channels <= self.out_channels:

@@ -439,8 +439,8 @@ def rows_gemm_supported(k: int, n: int) -> bool:
 
 def rows_gemm(x: Tensor, w: Tensor, trans_w: bool = False, out: Optional[Tensor] = None,
               accumulate: bool = False, table: Optional[Tensor] = None, table_row0: int = 0,
-              relu_push: bool = False) -> Tensor:
-    """``out = (out if accumulate else 0) + x @ w`` (``trans_w``: ``x @ w.T``) for a tall ``x``
+              relu_push: bool = False, bias: Optional[Tensor] = None) -> Tensor:
+    """``out = (out if accumulate else 0) + bias + x @ w`` (``trans_w``: ``x @ w.T``) for a tall ``x``
     ``[rows, k]`` and a small weight, on the matrix cores in exact fp32
     (incagg_rows_gemm_f32); ``table``: rows ``[table_row0, table_row0 + rows)`` of it receive
     the result too (``relu_push``: ``max(0, result)``) -- the History push of a layer's output,
@@ -462,6 +462,9 @@ def rows_gemm(x: Tensor, w: Tensor, trans_w: bool = False, out: Optional[Tensor]
         _rows_f32(out, "out", x.device)
         if out.size(0) != x.size(0) or out.size(1) != n:
             raise ValueError("out has the wrong shape")
+    if bias is not None and (bias.dtype != torch.float32 or bias.device != x.device
+                             or bias.dim() != 1 or bias.numel() != n or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous fp32 vector with one entry per output column")
     t_ptr = t_ld = t_rows = 0
     if table is not None:
         _rows_f32(table, "table", x.device)
@@ -470,7 +473,7 @@ def rows_gemm(x: Tensor, w: Tensor, trans_w: bool = False, out: Optional[Tensor]
         t_ptr, t_ld, t_rows = table.data_ptr(), _ld(table), table.size(0)
     with _on_device(x.device):
         check(lib().incagg_rows_gemm_f32(
-            _ptr(x), _ld(x), _ptr(w), w.stride(0), 1 if trans_w else 0, x.size(0), k, n,
+            _ptr(x), _ld(x), _ptr(w), w.stride(0), 1 if trans_w else 0, _ptr(bias), x.size(0), k, n,
             1 if accumulate else 0, _ptr(out), _ld(out), t_ptr or None, t_ld, t_rows,
             int(table_row0), 1 if relu_push else 0, _stream_of(x.device)))
     return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INCAGG_ABI_VERSION 4
+#define INCAGG_ABI_VERSION 5
 
 enum {
   INCAGG_OK = 0,
@@ -316,17 +316,19 @@ int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float 
 
 /* The dense update of a layer on the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32: a
  * k-ordered chain of fused multiply-adds, one rounding per product):
- *   y[rows, n] = (accumulate ? y : 0) + x[rows, k] @ W,   W = w ([k, n]) or w^T (w: [n, k], trans_w)
+ *   y[rows, n] = (accumulate ? y : 0) + bias[n] + x[rows, k] @ W,   W = w ([k, n]) or w^T (w: [n, k],
+ *   trans_w); bias optional (NULL: none)
  * and, when `table` is given, table[table_row0 + i, :n] = y[i, :] (relu_push: max(0, y[i, :])):
  * what follows the aggregation in a GCNII / GCN / GraphSAGE layer (models/gcn2.py:257,306
- * conv.forward_after_propagate; models/gcn.py:242-244; models/graphsage.py:634-642) together with
+ * conv.forward_after_propagate; models/gcn.py:242-244 with GCNConv's bias; models/graphsage.py:634-642) together with
  * the push of the layer's output into the next layer's table (history.py:41-65,
  * models/gcn2.py:129-138), and with trans_w the input-gradient product dX = dY W^T of its backward
  * pass.  k a positive multiple of 32, n a multiple of 4 up to 256 (incagg_rows_gemm_supported);
  * rows of x and w 16-byte aligned; y must not alias x, the table neither. */
 int incagg_rows_gemm_supported(int64_t k, int64_t n);
 int incagg_rows_gemm_f32(const float *x, int64_t ldx, const float *w, int64_t ldw, int trans_w,
-                         int64_t rows, int64_t k, int64_t n, int accumulate, float *y, int64_t ldy,
+                         const float *bias, int64_t rows, int64_t k, int64_t n, int accumulate,
+                         float *y, int64_t ldy,
                          float *table, int64_t ldt, int64_t table_rows, int64_t table_row0,
                          int relu_push, void *stream);
 

@@ -253,6 +253,16 @@ def test_rows_gemm_matches_float64(rows, k, n, trans_w):
     table.fill_(3.0)
     ops.rows_gemm(x, w, trans_w, out=blk, table=table, table_row0=0)
     assert torch.equal(table[:rows, :n], blk)
+    # a bias per output column: alone, and on top of the accumulated-into matrix
+    bias = torch.randn(n, generator=g).to(dev)
+    yb = ops.rows_gemm(x, w, trans_w, bias=bias)
+    assert float((yb.double() - (ref + bias.double())).abs().max()) <= tol + 1e-6
+    blk.copy_(before[:, n:2 * n])
+    ops.rows_gemm(x, w, trans_w, out=blk, accumulate=True, bias=bias)
+    assert float((blk.double() - (want + bias.double())).abs().max()) <= \
+        tol + 2e-6 * float(want.abs().max())
+    with pytest.raises(ValueError):
+        ops.rows_gemm(x, w, trans_w, bias=bias[:-1].contiguous())
     with pytest.raises(Exception):
         ops.rows_gemm(x, w, trans_w, out=blk, table=table, table_row0=21)
     with pytest.raises(Exception):
