@@ -34,6 +34,10 @@ def test_model_paths_tables_in_hbm(name, dev):
     mc.check_step_gradients(name, model, data, ptr, dev, vr=False)
     mc.check_incagg_forward(name, model, data, ptr, dev)
     mc.check_step_gradients(name, model, data, ptr, dev, vr=True)
+    # a batch that is ONE range of table rows: dense update, activation and push (push/pull
+    # step) or the next layer's relu(x) - M_in (incremental step) come from one fused launch
+    mc.check_step_gradients(name, model, data, ptr, dev, vr=False, parts=(2,))
+    mc.check_step_gradients(name, model, data, ptr, dev, vr=True, parts=(2,))
     mc.check_training_step(name, model, data, ptr, dev, vr=False)
     mc.check_training_step(name, model, data, ptr, dev, vr=True)
     _lib.check_device_errors()
