@@ -766,9 +766,12 @@ class ScalableGNN(torch.nn.Module):
         # rows read in place from that table -- instead of embedding the M >> B rows of every
         # batch's neighbourhood over again (the union of the batches covers every node once; the
         # values are the same either way).
+        # (only when the batches cover every node: a sweep over part of the graph must not read
+        # layer-0 rows that nobody wrote)
         embed_once = (in_place and not sharded and use_aggregation and not self.raw_input_layer
                       and self.device.type == 'cuda'
-                      and all(b[1] > 0 for b in batches))
+                      and all(b[1] > 0 for b in batches)
+                      and sum(b[1] for b in batches) == self.num_nodes)
         for data, batch_size, n_id, offset, count, state in batches:
             if batch_size == 0:      # padding batch of a partition-parallel run
                 continue
