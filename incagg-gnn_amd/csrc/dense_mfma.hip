@@ -54,6 +54,7 @@ struct GemmArgs {
   long long table_row0;
   int rows, k, n;
   int accumulate, relu_push;
+  int skip_y;          // the result goes to the table only (y is read when accumulating, never written)
 };
 
 struct __align__(16) GemmLds {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kGemmThreads) void rows_gemm_kernel(const GemmArgs 
       const int row = tile_row(r), col = wcol + 32 * cb + l32;
       if (!full && (row >= g.rows || col >= g.n)) continue;
       const float v = acc[cb][r];
-      g.y[(long long)row * g.ldy + col] = v;
+      if (!g.skip_y) g.y[(long long)row * g.ldy + col] = v;
       if (g.table)
         g.table[(g.table_row0 + row) * g.ldt + col] = g.relu_push ? fmaxf(v, 0.f) : v;
     }
@@ -218,7 +219,7 @@ extern "C" int incagg_rows_gemm_f32(const float *x, int64_t ldx, const float *w,
                                     int trans_w, const float *bias, int64_t rows, int64_t k,
                                     int64_t n, int accumulate, float *y, int64_t ldy, float *table,
                                     int64_t ldt, int64_t table_rows, int64_t table_row0,
-                                    int relu_push, void *stream) {
+                                    int relu_push, int table_only, void *stream) {
   INCAGG_REQUIRE(rows >= 0 && rows < INT_MAX - kTileRows, "rows %lld out of range", (long long)rows);
   INCAGG_REQUIRE(incagg_rows_gemm_supported(k, n),
                  "unsupported shape: k = %lld must be a positive multiple of %d, n = %lld a multiple "
@@ -241,6 +242,7 @@ extern "C" int incagg_rows_gemm_f32(const float *x, int64_t ldx, const float *w,
   g.table = table; g.ldt = ldt; g.table_row0 = table_row0;
   g.rows = (int)rows; g.k = (int)k; g.n = (int)n;
   g.accumulate = accumulate != 0; g.relu_push = relu_push != 0;
+  g.skip_y = table_only != 0 && table != nullptr;
   const dim3 grid((unsigned)((rows + kTileRows - 1) / kTileRows)), block(kGemmThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (trans_w) hipLaunchKernelGGL(rows_gemm_kernel<true>, grid, block, 0, s, g);

@@ -43,7 +43,7 @@ SIGNATURES = {
     "incagg_relu_rows_f32": (_int, [_vp, _i64, _i64, _i64, _vp]),
     "incagg_rows_gemm_supported": (_int, [_i64, _i64]),
     "incagg_rows_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _i64, _i64, _int, _vp,
-                                    _i64, _vp, _i64, _i64, _i64, _int, _vp]),
+                                    _i64, _vp, _i64, _i64, _i64, _int, _int, _vp]),
     "incagg_gate_add_rows_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "incagg_gcn2_fold_weights_f32": (_int, [_vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     "incagg_gcn2_fold_weights_backward_f32": (_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
@@ -86,7 +86,7 @@ class SpmmFuseStruct(_c.Structure):
 
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class AdamSegment(_c.Structure):

@@ -748,7 +748,7 @@ class ScalableGNN(torch.nn.Module):
                 hist = self.histories[i + 1]
                 if (agg.is_cuda and hist.emb.is_cuda and _same_device(hist.emb.device, agg.device)
                         and int(offset[0]) + batch_size <= hist.emb.size(0)):
-                    state['push_into'] = PushTarget(hist.emb, int(offset[0]), relu=True)
+                    state['push_into'] = PushTarget(hist.emb, int(offset[0]), relu=True, only=True)
             out = self._update(i, agg, x, state)[:batch_size]
             offered = state.pop('push_into', None)
             relu = state.pop('relu_deferred', False)

@@ -167,7 +167,8 @@ class _RowsLinear(torch.autograd.Function):
                 and push.fits(x.size(0), weight.size(0), x) and fused_layer_kernel_enabled()):
             # product, bias and the (activated) push of the result in one matrix-core launch
             out = ops.rows_gemm(x, weight, True, bias=bias, table=push.table,
-                                table_row0=push.row0, relu_push=push.relu)
+                                table_row0=push.row0, relu_push=push.relu,
+                                table_only=push.only and not torch.is_grad_enabled())
             push.done = True
             return out
         if not gathered:    # plain contiguous result (bias in the GEMM's epilogue)
@@ -252,8 +253,11 @@ class PushTarget:
     ``max(0, output)``).  ``done`` is set by the producer that took the offer; otherwise the
     caller pushes as usual."""
 
-    def __init__(self, table: Tensor, row0: int, relu: bool):
+    def __init__(self, table: Tensor, row0: int, relu: bool, only: bool = False):
         self.table, self.row0, self.relu, self.done = table, int(row0), bool(relu), False
+        # the caller reads the result from the table alone (a refresh sweep outside autograd):
+        # the producer need not write its own output matrix
+        self.only = bool(only)
 
     def fits(self, rows: int, width: int, like: Tensor) -> bool:
         t = self.table
@@ -287,7 +291,8 @@ class _TwoTermUpdate(torch.autograd.Function):
                     and ops.rows_gemm_supported(h.size(1), w1.size(1))
                     and push.fits(h.size(0), w1.size(1), h) and fused_layer_kernel_enabled()):
                 ops.rows_gemm(h, w1, False, out=term, accumulate=True, table=push.table,
-                              table_row0=push.row0, relu_push=push.relu)
+                              table_row0=push.row0, relu_push=push.relu,
+                              table_only=push.only and not torch.is_grad_enabled())
                 push.done = True
                 return term
             return term.addmm_(h, w1)

@@ -439,12 +439,14 @@ def rows_gemm_supported(k: int, n: int) -> bool:
 
 def rows_gemm(x: Tensor, w: Tensor, trans_w: bool = False, out: Optional[Tensor] = None,
               accumulate: bool = False, table: Optional[Tensor] = None, table_row0: int = 0,
-              relu_push: bool = False, bias: Optional[Tensor] = None) -> Tensor:
+              relu_push: bool = False, bias: Optional[Tensor] = None,
+              table_only: bool = False) -> Tensor:
     """``out = (out if accumulate else 0) + bias + x @ w`` (``trans_w``: ``x @ w.T``) for a tall ``x``
     ``[rows, k]`` and a small weight, on the matrix cores in exact fp32
     (incagg_rows_gemm_f32); ``table``: rows ``[table_row0, table_row0 + rows)`` of it receive
     the result too (``relu_push``: ``max(0, result)``) -- the History push of a layer's output,
-    done by the producer.  ``out`` defaults to a fresh matrix at the gather pitch."""
+    done by the producer; ``table_only``: ``out`` is then not written (it still supplies the
+    accumulated-into values).  ``out`` defaults to a fresh matrix at the gather pitch."""
     _need_cuda(x, "x")
     _rows_f32(x, "x")
     if w.dim() != 2 or w.dtype != torch.float32 or w.device != x.device or w.stride(1) != 1:
@@ -475,7 +477,8 @@ def rows_gemm(x: Tensor, w: Tensor, trans_w: bool = False, out: Optional[Tensor]
         check(lib().incagg_rows_gemm_f32(
             _ptr(x), _ld(x), _ptr(w), w.stride(0), 1 if trans_w else 0, _ptr(bias), x.size(0), k, n,
             1 if accumulate else 0, _ptr(out), _ld(out), t_ptr or None, t_ld, t_rows,
-            int(table_row0), 1 if relu_push else 0, _stream_of(x.device)))
+            int(table_row0), 1 if relu_push else 0, 1 if table_only and table is not None else 0,
+            _stream_of(x.device)))
     return out
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INCAGG_ABI_VERSION 5
+#define INCAGG_ABI_VERSION 6
 
 enum {
   INCAGG_OK = 0,
@@ -323,14 +323,17 @@ int incagg_adam_step_f32(const incagg_adam_segment *segs, int64_t n_segs, float 
  * conv.forward_after_propagate; models/gcn.py:242-244 with GCNConv's bias; models/graphsage.py:634-642) together with
  * the push of the layer's output into the next layer's table (history.py:41-65,
  * models/gcn2.py:129-138), and with trans_w the input-gradient product dX = dY W^T of its backward
- * pass.  k a positive multiple of 32, n a multiple of 4 up to 256 (incagg_rows_gemm_supported);
+ * pass.  table_only (with a table): y is not written -- it still supplies the values accumulated
+ * into -- for callers that only need the stored rows (the layer-wise refresh sweep,
+ * models/gcn2.py:433-507, reads every layer's input from the tables).
+ * k a positive multiple of 32, n a multiple of 4 up to 256 (incagg_rows_gemm_supported);
  * rows of x and w 16-byte aligned; y must not alias x, the table neither. */
 int incagg_rows_gemm_supported(int64_t k, int64_t n);
 int incagg_rows_gemm_f32(const float *x, int64_t ldx, const float *w, int64_t ldw, int trans_w,
                          const float *bias, int64_t rows, int64_t k, int64_t n, int accumulate,
                          float *y, int64_t ldy,
                          float *table, int64_t ldt, int64_t table_rows, int64_t table_row0,
-                         int relu_push, void *stream);
+                         int relu_push, int table_only, void *stream);
 
 /* x = max(x, 0) in place over [rows, width] (pitch ld): the activation in front of a model's
  * classifier (models/gcn2.py:136), at streaming rate. */

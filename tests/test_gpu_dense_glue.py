@@ -253,6 +253,14 @@ def test_rows_gemm_matches_float64(rows, k, n, trans_w):
     table.fill_(3.0)
     ops.rows_gemm(x, w, trans_w, out=blk, table=table, table_row0=0)
     assert torch.equal(table[:rows, :n], blk)
+    # table only: the accumulated-into matrix is read, not written
+    blk.copy_(before[:, n:2 * n])
+    table.fill_(3.0)
+    ops.rows_gemm(x, w, trans_w, out=blk, accumulate=True, table=table, table_row0=3,
+                  relu_push=True, table_only=True)
+    assert torch.equal(blk, before[:, n:2 * n])
+    assert float((table[3:3 + rows, :n].double() - torch.relu(want)).abs().max()) <= \
+        tol + 1e-6 * float(want.abs().max())
     # a bias per output column: alone, and on top of the accumulated-into matrix
     bias = torch.randn(n, generator=g).to(dev)
     yb = ops.rows_gemm(x, w, trans_w, bias=bias)
