@@ -158,15 +158,34 @@ class KernelClock:
 
         ops.spmm_csr_incagg = timed_inc
 
-    def summary(self):
+    @staticmethod
+    def empty_interval_ms(pairs=256, spin=0):
+        """What a start/end event pair with NOTHING between them reads on this stream, behind
+        ``spin`` cycles of spin work so that the host is ahead of the device as in the timed
+        pass: the events' own share of every interval (each is a packet of its own that the
+        command processor has to retire; 4-5 us per pair on MI355X)."""
+        if spin:
+            torch.cuda._sleep(spin)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(pairs)]
+        for s, e in ev:
+            s.record()
+            e.record()
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in ev)
+        return ms[len(ms) // 2]
+
+    def summary(self, empty_ms=0.0):
+        """``empty_ms``: the reading of an empty event pair, taken off every interval."""
         if not self.records:
             return None
-        ms = [s.elapsed_time(e) for s, e, *_ in self.records]
+        raw = [s.elapsed_time(e) for s, e, *_ in self.records]
+        ms = [max(t - empty_ms, 1e-6) for t in raw]
         algo = sum(r[2] for r in self.records)
         gather = sum(r[3] for r in self.records)
         tot_s = sum(ms) / 1e3
         return {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "algo_GBps": algo / tot_s / 1e9,
-                "gather_GBps": gather / tot_s / 1e9,
+                "gather_GBps": gather / tot_s / 1e9, "avg_interval_ms": sum(raw) / len(raw),
                 "algo_bytes_per_launch": algo / len(ms)}
 
 
@@ -669,6 +688,7 @@ def main():
     elapsed = time.perf_counter() - t0
     clock.enabled = False
     kernel_timing = "HIP events around every aggregation launch of the timed steps"
+    empty_ms = 0.0
     if graphs is not None:
         # The timed steps were graph replays, into which no timing events can be placed: the
         # per-launch durations come from an eager pass over the same K steps, right away.
@@ -696,11 +716,15 @@ def main():
             unrecorded((args.warmup + i) % len(batches))
         torch.cuda.synchronize()
         clock.enabled = False
+        empty_ms = clock.empty_interval_ms(spin=int(spin_per_ms * 8))
         kernel_timing = ("HIP events around every aggregation launch in an eager pass over the "
                          "same K steps run right after the timed region, each step enqueued "
                          f"behind {1.5 * t_issue:.1f} ms of spin work (1.5x the host's issue time of "
                          "an eager step) so that the intervals hold device time only (the timed "
-                         "steps are HIP graph replays, which cannot carry timing events)")
+                         "steps are HIP graph replays, which cannot carry timing events); "
+                         f"avg_launch_ms = the mean interval (avg_interval_ms) less the "
+                         f"{empty_ms * 1e3:.1f} us that an event pair with nothing between it "
+                         "reads on the same stream (median of 256 pairs)")
     # ---- epoch time, part (i): one training pass over every partition batch of this rank
     # (outside the timed region; the same step() the K timed steps ran)
     epoch_s = None
@@ -751,7 +775,7 @@ def main():
                         else "eager")
         _lib.check_device_errors()
 
-    ks = clock.summary()
+    ks = clock.summary(empty_ms)
     if rank == 0:
         bt = batches[0]
         line = {
@@ -800,7 +824,8 @@ def main():
                 "frac": ks["algo_GBps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(args),
                 "kernel": ("spmm_narrow_kernel" if 32 < model.histories[-1].embedding_dim <= 48 else "spmm_plan_kernel")
                 + ", forward and transposed launches (one launch per call)",
-                "avg_launch_ms": ks["avg_ms"], "launches": ks["launches"],
+                "avg_launch_ms": ks["avg_ms"], "avg_interval_ms": ks["avg_interval_ms"],
+                "empty_event_pair_ms": empty_ms, "launches": ks["launches"],
                 "algorithmic_bytes_per_launch": ks["algo_bytes_per_launch"],
                 "gather_bound_GBps": ks["gather_GBps"],
                 "timing": kernel_timing,
