@@ -93,6 +93,64 @@ print(f"one launch {timeit(one):.1f} us | in-batch part {timeit(first):.1f} us |
       f"{timeit(second):.1f} us | both {timeit(two):.1f} us", flush=True)
 _lib.check_device_errors()
 
+# ---- the two parts as concurrent launches on two streams (no dependency between them): do
+# L2-served gathers and HBM-cold gathers overlap when they come from different waves?
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+outs = [ops.rows_empty(B, F, dev) for _ in range(2)]
+
+
+def concurrent():
+    main = torch.cuda.current_stream()
+    sa.wait_stream(main)
+    sb.wait_stream(main)
+    with torch.cuda.stream(sa):
+        ops.spmm_csr(rp_i, c_i, v_i, xb, B, plan=plan_i, relu_x=True, out=outs[0])
+    with torch.cuda.stream(sb):
+        k[0] += 1
+        ops.spmm_csr(rp_o, c_o_tab, v_o, tables[k[0] % 6], N, out=outs[1], plan=plan_o)
+    main.wait_stream(sa)
+    main.wait_stream(sb)
+
+
+def serial_pair():
+    ops.spmm_csr(rp_i, c_i, v_i, xb, B, plan=plan_i, relu_x=True, out=outs[0])
+    k[0] += 1
+    ops.spmm_csr(rp_o, c_o_tab, v_o, tables[k[0] % 6], N, out=outs[1], plan=plan_o)
+
+
+gc, gs = None, None
+for name, fn in (("two streams", concurrent), ("one stream", serial_pair)):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(6):
+            fn()
+    print(f"independent parts, {name}: {timeit(g.replay, 10) / 6:.1f} us per pair", flush=True)
+_lib.check_device_errors()
+# ---- ONE launch whose rows are the in-batch parts followed by the out-of-batch parts (2B rows):
+# every wave then gathers either L2-resident fresh rows or HBM-cold table rows, never both
+rp2 = torch.cat([rp_i, rp_i[-1] + rp_o[1:]]).contiguous()
+col2 = torch.cat([c_i, c_o]).contiguous()
+val2 = torch.cat([v_i, v_o]).contiguous()
+plan2 = ops.SpmmPlan.build(rp2, E).with_edges(ops.pack_edges(col2, val2))
+out2 = ops.rows_empty(2 * B, F, dev)
+
+
+def separated():
+    k[0] += 1
+    return ops.spmm_csr(rp2, col2, val2, xb, B + N, x_halo=tables[k[0] % 6], plan=plan2, relu_x=True,
+                        out=out2)
+
+
+k[0] = 0
+got2 = separated()
+print("separated rows: max diff", float((ref - (got2[:B] + got2[B:])).abs().max()), flush=True)
+print(f"one launch over 2B part-rows: {timeit(separated):.1f} us", flush=True)
+_lib.check_device_errors()
+if os.environ.get("SPLIT_ONLY"):
+    sys.exit(0)
+
 # ---- a chain of 8 layers: aggregation then a [B,256]x[256,256] product, with the out-of-batch
 # partial sums either inside each aggregation launch or computed on a side stream up front
 W = torch.randn(F, F, device=dev) * 0.05
