@@ -75,6 +75,10 @@ def parse():
                          "partitions; auto = only on a single GPU")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the partition-parallel code path even with one rank")
+    ap.add_argument("--halo-ahead", choices=["on", "off"], default="on",
+                    help="partition-parallel push/pull steps: exchange the out-of-batch rows of the "
+                         "next step's batch while the current step computes (off: at the top of "
+                         "the step that reads them)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fused-incagg", action="store_true",
                     help="vr mode: A (x - M_in) + M_ag as one launch gathering both operands "
@@ -436,6 +440,7 @@ def main():
         })
 
     table_rows = ctx.local_rows if sharded else n      # row-sharded tables, never replicated
+    halo_pipe = None
     table_dev = None if host_tables else dev
     pool = {}
     if host_tables:     # staging slots as main.py:177 sizes them: 2 x the largest batch (rows + halo)
@@ -465,7 +470,13 @@ def main():
         if not host_tables:
             # out-of-batch rows are read in place as on a single GPU: own rows where they are,
             # rows of peers received into the tail of the table shard
-            D.reserve_halo_tails(model, [bt["host"] for bt in batches])
+            # (and, for the push/pull step, the rows of the next step's batch travel while the
+            # current step computes: HaloPipeline gives consecutive batches separate tail regions)
+            if args.mode != "vr":
+                halo_pipe = D.HaloPipeline(model, [bt["adj"] for bt in batches],
+                                           ahead=args.halo_ahead == "on")
+            else:
+                D.reserve_halo_tails(model, [bt["host"] for bt in batches])
     model.fused_incagg = args.fused_incagg
     g_cpu = torch.Generator().manual_seed(2)
     with torch.no_grad():
@@ -552,9 +563,8 @@ def main():
 
     def split_step(k, replay):
         bt = batches[k]
-        if args.mode != "vr":
-            for pending in model.start_halo_exchanges(bt["adj"]):
-                pending.wait()
+        if halo_pipe is not None:
+            halo_pipe.ready(k)      # this batch's foreign rows are in; the next batch's set off
         if replay:
             graphs.replay(k)
             grad = flat_grads[k]    # (recorded: the same memory in every replay)
@@ -620,6 +630,8 @@ def main():
         graphs = StepGraphs(dev)
         for k in range(len(batches)):
             graphs.warm(lambda: split_step(k, replay=False), times=1)
+        if halo_pipe is not None:
+            halo_pipe.drain()
         D.quiesce_collectives()
         recorded = True
         try:
@@ -756,6 +768,8 @@ def main():
     # (outside the timed region above; it is reported next to the headline value)
     sweep_s = sweep_edges = None
     sweep_launch = None
+    if halo_pipe is not None:
+        halo_pipe.drain()
     if evals is not None:
         torch.cuda.synchronize()
         if sharded:
@@ -796,8 +810,10 @@ def main():
                 "batch_rows": bt["b"], "batch_rows_with_halo": int(bt["n_id"].numel()),
                 "batch_edges": bt["adj"].nnz(),
                 "parallelism": f"partition-parallel x{world}" + (
-                    ", row-sharded History tables, one all-to-all of halo rows per layer, "
-                    "flat gradient all-reduce" if sharded else ""),
+                    ", row-sharded History tables, one all-to-all of halo rows per layer"
+                    + (" issued one step ahead (the rows a step reads left their owners at the "
+                       "top of the step before)" if halo_pipe is not None and halo_pipe.ahead
+                       else "") + ", flat gradient all-reduce" if sharded else ""),
                 "setup_seconds": round(setup_s, 1),
                 "step_launch": ("collectives issued eagerly around one HIP graph replay of "
                                 "forward + loss + backward per step" if flat_grads is not None

@@ -86,6 +86,10 @@ class HaloPlan:
         self.serve_local = serve_local      # local row ids to send, grouped by destination rank
         self.send_counts = send_counts
         self.n_halo = own_local.numel() + sum(recv_counts)
+        # which tail region of the tables receives this batch's foreign rows (History.reserve_tail;
+        # fixed before the batch's first in-place exchange: the row ids handed to the
+        # aggregation -- and whatever was recorded with them -- point into that region)
+        self.region = 0
         self._dev = {}
 
     def _on(self, device):
@@ -129,25 +133,30 @@ class HaloPlan:
         """Out-of-batch rows of the batch that peers own."""
         return sum(self.recv_counts)
 
-    def in_place_ids(self, n_local: int, device) -> Tensor:
+    def in_place_ids(self, history) -> Tensor:
         """Row ids of the batch's out-of-batch rows in a table whose tail holds the received
-        rows (History.reserve_tail): own rows where they are, row ``n_local + k`` for the k-th
-        received one -- what the aggregation takes as ``halo_ids``."""
-        key = ("ids", str(device), n_local)
+        rows (History.reserve_tail): own rows where they are, row ``tail start + k`` for the
+        k-th received one (tail start: the first row of this plan's region) -- what the
+        aggregation takes as ``halo_ids``."""
+        n_local, device = history.num_embeddings, history.emb.device
+        start = n_local + self.region * history.tail_rows
+        key = ("ids", str(device), start)
         if key not in self._dev:
             self._dev[key] = torch.cat([
-                self.own_local, n_local + torch.arange(self.n_remote, dtype=torch.int64)]
+                self.own_local, start + torch.arange(self.n_remote, dtype=torch.int64)]
             ).to(device)
         return self._dev[key]
 
     def start_exchange_in_place(self, history) -> "PendingHalo":
         """:meth:`start_exchange` without a halo buffer: rows this rank owns are not moved at
-        all, rows of peers land in the tail of ``history``'s own allocation (whole rows at the
-        table's pitch, so that both ends of the transfer are contiguous).  Collective."""
+        all, rows of peers land in the tail of ``history``'s own allocation, in this plan's
+        region (whole rows at the table's pitch, so that both ends of the transfer are
+        contiguous).  Collective."""
         base, n_local = history._base, history.num_embeddings
-        if base is None or history.tail_rows < self.n_remote:
-            raise RuntimeError(f"the table has room for {history.tail_rows} foreign rows, the "
-                               f"batch needs {self.n_remote} (History.reserve_tail)")
+        if base is None or history.tail_rows < self.n_remote or self.region >= history.tail_regions:
+            raise RuntimeError(f"the table has {history.tail_regions} region(s) of "
+                               f"{history.tail_rows} foreign rows, the batch needs {self.n_remote} "
+                               f"in region {self.region} (History.reserve_tail)")
         work = send = None
         if self.ctx.world > 1 or self.ctx.exercise_collectives:
             device = base.device if base.is_cuda or not torch.cuda.is_available() \
@@ -156,7 +165,8 @@ class HaloPlan:
             send = ops.gather_rows(base[:n_local], serve_local, device=device) \
                 if serve_local.numel() else torch.empty((0, base.size(1)), dtype=base.dtype,
                                                         device=device)
-            recv = base[n_local:n_local + self.n_remote]
+            start = n_local + self.region * history.tail_rows
+            recv = base[start:start + self.n_remote]
             work = dist.all_to_all_single(recv, send, self.recv_counts, self.send_counts,
                                           group=self.ctx.group, async_op=True)
         return PendingHalo(work, None, send)
@@ -259,22 +269,95 @@ def sharded_eval_batches(data: Data, ptr: Tensor, ctx: PartitionContext,
     return [sharded_partition_batch(data, ptr, g, ctx) for g in groups]
 
 
-def reserve_halo_tails(model, batches) -> int:
-    """Gives every layer-input table of ``model`` room for the largest number of foreign
-    out-of-batch rows any of ``batches`` (SubData from :func:`sharded_partition_batch`) needs;
-    the push/pull step and the sweeps then read out-of-batch rows in place.  Returns that
-    number.  Collective."""
+def _plan_of(sub) -> Optional[HaloPlan]:
+    """The halo plan of a SubData, an adjacency or a plan itself."""
+    if isinstance(sub, HaloPlan):
+        return sub
+    return getattr(getattr(getattr(sub, "data", None), "adj_t", sub), "_halo_plan", None)
+
+
+def reserve_halo_tails(model, batches, regions: int = 1) -> int:
+    """Gives every layer-input table of ``model`` room (``regions`` times over) for the largest
+    number of foreign out-of-batch rows any of ``batches`` (SubData from
+    :func:`sharded_partition_batch`) needs; the push/pull step and the sweeps then read
+    out-of-batch rows in place.  Returns that number.  Collective."""
     need, ctx = 0, None
     for sub in batches:     # SubData, adjacencies or the plans themselves
-        plan = sub if isinstance(sub, HaloPlan) else getattr(
-            getattr(getattr(sub, "data", None), "adj_t", sub), "_halo_plan", None)
+        plan = _plan_of(sub)
         if plan is not None:
             need, ctx = max(need, plan.n_remote), plan.ctx
     if ctx is not None:     # every rank reserves (and so takes the in-place form of the exchange)
         need = ctx.max_over_ranks(need)
     for h in model.histories:
-        h.reserve_tail(need)
+        h.reserve_tail(need, regions)
     return need
+
+
+class HaloPipeline:
+    """Push/pull training steps over a fixed cyclic sequence of batches with the exchange of
+    out-of-batch rows running ONE STEP AHEAD: while step ``i`` computes, the rows that step
+    ``i + 1`` will read travel over the links into another region of the table tails.
+
+    What a step reads is then well defined and the same on every run: the out-of-batch rows
+    of step ``i + 1`` are gathered on their owners at the top of step ``i``, i.e. they hold the
+    tables as the pushes of steps ``< i`` left them -- one step older than with an exchange at
+    the top of step ``i + 1`` itself.  (Ranks run their batches side by side, so "the value a
+    peer holds right now" is no better defined in either form; historical rows are stale by
+    construction, history.py:9-74.)
+
+    Regions: consecutive batches of the cycle must not share one.  Batch ``k`` gets region
+    ``k % 2``; with an odd number of batches the last one gets a third region (it is followed
+    by batch 0).  Every rank must bring the same number of batches: the exchange plan of a
+    rank's k-th batch was built together with its peers' k-th batches
+    (:func:`build_halo_plan`), and that is the round they have to be exchanged in.  With a
+    single batch per rank there is nothing to look ahead to, and the pipeline degenerates to an
+    exchange at the top of every step.
+
+    Use: ``pipe = HaloPipeline(model, adjs)`` once (collective; assigns regions and reserves
+    the tails), then per step ``pipe.ready(k)`` followed by ``model(..., halo_ready=True)`` for
+    batch ``k``; ``pipe.drain()`` before anything that must not overlap a collective (recording
+    a HIP graph)."""
+
+    def __init__(self, model, adjs, ahead: bool = True):
+        self.model, self.adjs = model, list(adjs)
+        plans = [_plan_of(a) for a in self.adjs]
+        if any(p is None for p in plans):
+            raise RuntimeError("every batch needs a halo plan (sharded_partition_batch)")
+        ctx = plans[0].ctx
+        n = len(plans)
+        if ctx.max_over_ranks(n) != n or -ctx.max_over_ranks(-n) != n:
+            raise RuntimeError("every rank must bring the same number of batches")
+        self.ahead = bool(ahead) and n >= 2
+        regions = 1
+        if self.ahead:
+            for k, p in enumerate(plans):
+                p.region = 2 if (n % 2 == 1 and k == n - 1) else k % 2
+            regions = 3 if n % 2 else 2
+        reserve_halo_tails(model, plans, regions)
+        self._pending = {}      # batch index -> its exchanges in flight, one per layer
+
+    def ready(self, k: int) -> None:
+        """Orders the current stream behind the arrival of batch ``k``'s out-of-batch rows and
+        starts the exchange for the batch that follows it in the cycle.  Collective."""
+        cur = self._pending.pop(k, None)
+        if self._pending:       # the look-ahead was for another batch: those rows are dropped
+            self.drain()        # (their region may be written again before they are read)
+        if cur is None:
+            cur = self.model.start_halo_exchanges(self.adjs[k])
+        for pending in cur:
+            pending.wait()
+        if self.ahead:
+            nxt = (k + 1) % len(self.adjs)
+            if nxt not in self._pending:
+                self._pending[nxt] = self.model.start_halo_exchanges(self.adjs[nxt])
+
+    def drain(self) -> None:
+        """Waits for every exchange in flight (their rows are dropped: the next
+        :meth:`ready` fetches afresh)."""
+        for k in sorted(self._pending):
+            for pending in self._pending[k]:
+                pending.wait()
+        self._pending = {}
 
 
 def allreduce_gradients(module: torch.nn.Module, ctx: PartitionContext) -> None:

@@ -40,30 +40,36 @@ class History(torch.nn.Module):
             self.emb = ops.rows_empty(num_embeddings, embedding_dim, device)
         # partition-parallel runs (reserve_tail): rows received from peers are parked right
         # behind the table's own rows, in the same allocation
-        self.tail_rows = 0
-        self.emb_with_tail = self.emb      # [num_embeddings + tail_rows, dim]
+        self.tail_rows = 0                 # rows per tail region
+        self.tail_regions = 0
+        self.emb_with_tail = self.emb      # [num_embeddings + tail_regions * tail_rows, dim]
         self._base = None                  # the contiguous [rows, pitch] matrix behind it
         self._device = torch.device("cpu")
         self.reset_parameters()
 
     @torch.no_grad()
-    def reserve_tail(self, rows: int) -> None:
-        """Room for ``rows`` foreign rows behind the table's own (``emb`` keeps its contents
-        and shape; it moves to a new allocation).  A partition-parallel step receives the
-        out-of-batch rows its peers own there, so that the aggregation can read own and
-        foreign out-of-batch rows from ONE matrix in place."""
-        if rows <= self.tail_rows and self._base is not None:
+    def reserve_tail(self, rows: int, regions: int = 1) -> None:
+        """Room for ``regions`` x ``rows`` foreign rows behind the table's own (``emb`` keeps its
+        contents and shape; it moves to a new allocation).  A partition-parallel step receives
+        the out-of-batch rows its peers own there, so that the aggregation can read own and
+        foreign out-of-batch rows from ONE matrix in place.  Several regions let the rows of the
+        next step's batch arrive while the current step still reads its own
+        (distributed.HaloPipeline); region ``r`` starts at row ``num_embeddings + r * rows``."""
+        regions = max(1, int(regions))
+        if rows <= self.tail_rows and regions <= self.tail_regions and self._base is not None:
             return
+        rows, regions = max(rows, self.tail_rows), max(regions, self.tail_regions)
         n, dim = self.num_embeddings, self.embedding_dim
         if self.emb.is_cuda:
-            full, base = ops.rows_empty(n + rows, dim, self.emb.device, self.emb.dtype,
+            full, base = ops.rows_empty(n + regions * rows, dim, self.emb.device, self.emb.dtype,
                                         with_base=True)
         else:
-            full = base = torch.empty((n + rows, dim), dtype=self.emb.dtype,
+            full = base = torch.empty((n + regions * rows, dim), dtype=self.emb.dtype,
                                       pin_memory=self.emb.is_pinned())
         full[:n] = self.emb
         full[n:] = 0
-        self.emb, self.emb_with_tail, self._base, self.tail_rows = full[:n], full, base, rows
+        self.emb, self.emb_with_tail, self._base = full[:n], full, base
+        self.tail_rows, self.tail_regions = rows, regions
 
     def reset_parameters(self):
         self.emb.fill_(0)

@@ -398,7 +398,7 @@ class ScalableGNN(torch.nn.Module):
                 if plan.n_halo == 0:
                     return x, None, None
                 return (x, history.emb_with_tail[:, :x.size(1)],
-                        plan.in_place_ids(history.num_embeddings, history.emb.device))
+                        plan.in_place_ids(history))
             if self._halo_pending:
                 return x, self._halo_pending.pop(0).wait(), None
             return x, (None if plan is None else plan.exchange(history.emb)), None
@@ -834,7 +834,7 @@ class ScalableGNN(torch.nn.Module):
                         plan.start_exchange_in_place(hist).wait()
                         if plan.n_halo:
                             halo = hist.emb_with_tail
-                            halo_ids = plan.in_place_ids(hist.num_embeddings, hist.emb.device)
+                            halo_ids = plan.in_place_ids(hist)
                 else:
                     x = self._pull_layer_input(self.histories[i], batch_size, n_id, offset, count,
                                                plan)

@@ -23,6 +23,69 @@ import model_cases as mc  # noqa: E402
 from cpu_shim import cpu_kernels  # noqa: E402
 
 
+PIPELINE_PARTS = 7      # partitions of the pipeline case
+PIPELINE_MODEL = "gcn2"
+
+
+def pipeline_steps(world):
+    """Steps of the pipeline case: every rank's cycle wraps around at least twice."""
+    return 2 * (PIPELINE_PARTS // world + 1) + 1
+
+
+def pipeline_tables(model, n):
+    """Whole tables of the pipeline case to start from: random rows, far from what the model
+    would push, so that every step's pushes change what later steps read."""
+    g = torch.Generator().manual_seed(11)
+    return [torch.randn(n, h.embedding_dim, generator=g) for h in model.histories]
+
+
+def pipeline_main(out_dir, dev, on_gpu):
+    """Push/pull forward steps over this rank's partitions, one per step, with the exchange of
+    out-of-batch rows running one step ahead (distributed.HaloPipeline); the outputs of every
+    step and the tables at the end go to the result file."""
+    from torch_geometric_autoscale import distributed as D
+    data, ptr = mc.make_graph(parts=PIPELINE_PARTS)
+    ctx = D.PartitionContext(ptr, exercise_collectives=on_gpu and dist.get_world_size() == 1)
+    result = {"row_lo": ctx.row_lo, "row_hi": ctx.row_hi, "parts": ctx.local_parts}
+    with (contextlib.nullcontext() if on_gpu else cpu_kernels()):
+        model = mc.make_model(PIPELINE_MODEL, data, data.x.size(1), 5,
+                              emb_device=dev if on_gpu else "cpu", num_nodes=ctx.local_rows)
+        if on_gpu:
+            model = model.to(dev)
+        model.set_partition_context(ctx)
+        model.eval()
+        # (a batch's exchange plan is built, and later used, together with the peers' batches of
+        # the same round: every rank brings as many batches as the rank with the smallest share)
+        mine = ctx.local_parts[:-ctx.max_over_ranks(-len(ctx.local_parts))]
+        result["parts"] = mine
+        subs = [D.sharded_partition_batch(data, ptr, [p], ctx) for p in mine]
+        pipe = D.HaloPipeline(model, [s.data.adj_t for s in subs])
+        result["ahead"] = pipe.ahead
+        result["regions"] = [s.data.adj_t._halo_plan.region for s in subs]
+        for t, full in zip(model.histories, pipeline_tables(model, data.num_nodes)):
+            t.emb.copy_(full[ctx.row_lo:ctx.row_hi])
+        for i in range(pipeline_steps(ctx.world)):
+            sub = subs[i % len(subs)]
+            b = sub.batch_size
+            pipe.ready(i % len(subs))
+            x = sub.data.x.to(dev) if on_gpu else sub.data.x
+            adj = sub.data.adj_t.to(dev) if on_gpu else sub.data.adj_t
+            with torch.no_grad():
+                ret = model(x, adj, b, sub.n_id, sub.offset, sub.count, halo_ready=True)
+            result[f"step{i}"] = ret["out"].detach().clone()
+        pipe.drain()
+        for i in range(1, model.num_layers):
+            result[f"hist{i}"] = model.histories[i].emb.clone()
+    if on_gpu:
+        from torch_geometric_autoscale import _lib
+        torch.cuda.synchronize()
+        _lib.check_device_errors()
+        result = {k: v.cpu() if torch.is_tensor(v) else v for k, v in result.items()}
+    torch.save(result, os.path.join(out_dir, f"rank{ctx.rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out_dir = sys.argv[1]
     names = sys.argv[2].split(",")
@@ -38,6 +101,8 @@ def main():
         dev = torch.device("cpu")
         dist.init_process_group("gloo")
     from torch_geometric_autoscale import distributed as D
+    if len(sys.argv) > 3 and sys.argv[3] == "pipeline":
+        return pipeline_main(out_dir, dev, on_gpu)
     data, ptr = mc.make_graph()
     ctx = D.PartitionContext(ptr, exercise_collectives=on_gpu and dist.get_world_size() == 1)
     result = {"row_lo": ctx.row_lo, "row_hi": ctx.row_hi}

@@ -101,6 +101,78 @@ def test_sharded_run_matches_single_process(world, mode, tmp_path):
     check_against_single_process(ranks, world)
 
 
+def check_pipeline_against_single_process(ranks, world, dev=None):
+    """The steps of tests/dist_worker.py's pipeline case against one process that holds whole
+    tables and hands every step its out-of-batch rows as the exchange running one step ahead
+    delivers them: rows of peers as the pushes of the steps before the previous one left them,
+    rows of the rank itself (read in place) as the previous step left them.  Without the
+    look-ahead (one batch per rank) all of them as the previous step left them."""
+    import contextlib
+    import dist_worker as dw
+    from torch_geometric_autoscale.loader import partition_batch
+    data, ptr = mc.make_graph(parts=dw.PIPELINE_PARTS)
+    on_gpu = dev is not None
+    ahead = ranks[0]["ahead"]
+    assert all(r["ahead"] == ahead for r in ranks)
+    for r in ranks:     # consecutive batches of a rank's cycle never share a region
+        reg = r["regions"]
+        if ahead:
+            assert all(reg[k] != reg[(k + 1) % len(reg)] for k in range(len(reg))), reg
+    with (contextlib.nullcontext() if on_gpu else cpu_kernels()):
+        model = mc.make_model(dw.PIPELINE_MODEL, data, data.x.size(1), 5,
+                              emb_device=dev if on_gpu else "cpu")
+        if on_gpu:
+            model = model.to(dev)
+        model.eval()
+        tables = [h.emb for h in model.histories]
+        live = [t.to(tables[0].device) for t in dw.pipeline_tables(model, data.num_nodes)]
+        before = [[t.clone() for t in live]]        # before[i]: tables before step i's pushes
+        for i in range(dw.pipeline_steps(world)):
+            if i:
+                before.append([t.clone() for t in live])
+            for res in ranks:
+                part = res["parts"][i % len(res["parts"])]
+                sub = partition_batch(data, ptr, [part])
+                b = sub.batch_size
+                lo, hi = res["row_lo"], res["row_hi"]
+                for t, old, new in zip(tables, before[max(i - 1, 0)], before[i]):
+                    t.copy_(old if ahead else new)
+                    t[lo:hi] = new[lo:hi]
+                with torch.no_grad():
+                    ret = model(sub.data.x.to(dev) if on_gpu else sub.data.x,
+                                sub.data.adj_t.to(dev) if on_gpu else sub.data.adj_t, b, sub.n_id,
+                                sub.offset, sub.count)
+                np.testing.assert_allclose(res[f"step{i}"].numpy(), ret["out"].cpu().numpy(), **TOL,
+                                           err_msg=f"step {i}, partition {part}")
+                rows = sub.n_id[:b].to(tables[0].device)
+                for t, l_ in zip(tables, live):     # this step's pushes
+                    l_[rows] = t[rows]
+        for res in ranks:
+            lo, hi = res["row_lo"], res["row_hi"]
+            for k in range(1, model.num_layers):
+                np.testing.assert_allclose(res[f"hist{k}"].numpy(), live[k][lo:hi].cpu().numpy(), **TOL)
+
+
+def _run_pipeline_ranks(world, tmp_path, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS="2", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "-", "pipeline"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    return [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_exchange_one_step_ahead_matches_single_process(world, tmp_path):
+    """Shares of 3 + 4, 2 + 2 + 3 and 1 + 2 + 1 + 2 partitions, of which every rank uses as many
+    as the smallest share: cycles of 3 (odd: three tail regions), 2 and 1 batches (nothing to
+    look ahead to: exchanges at the top of every step)."""
+    ranks = _run_pipeline_ranks(world, tmp_path)
+    assert ranks[0]["ahead"] == (world < 4)
+    check_pipeline_against_single_process(ranks, world)
+
+
 def test_halo_plan_orders_own_rows_first():
     from torch_geometric_autoscale import distributed as D
     ptr = torch.tensor([0, 10, 20, 30, 40])

@@ -112,12 +112,17 @@ def test_sharded_path_over_rccl_matches_unsharded(name, tables, rccl):
             assert calls["in_place"] > 0
 
 
-def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
+@pytest.mark.parametrize("ahead", [False, True])
+def test_recorded_step_between_eager_collectives_trains_like_eager_steps(ahead, rccl):
     """A partition-parallel step split at its collectives: halo exchanges (into the table
     tails) and the flat gradient all-reduce are issued eagerly, everything between them --
     forward with ``halo_ready=True``, loss, backward into the flat gradient buffer -- is ONE
     HIP graph recorded next to the live RCCL process group.  Weights and tables after three
-    such steps over two batches equal those of eagerly issued partition-parallel steps."""
+    such steps over two batches equal those of eagerly issued partition-parallel steps.
+    ``ahead``: the exchanges of the next step's batch are issued before the current step's
+    graph is replayed (with one rank there are no foreign rows, so both forms read the same
+    values; what differs is which tail region a batch's row ids point into and that collectives
+    are in flight during the replays)."""
     import copy
     import torch_geometric_autoscale as tga
     from torch_geometric_autoscale import _lib, distributed as D
@@ -136,7 +141,7 @@ def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
                                 list(base.histories) + list(base.histories_ag)):
             h_new.emb = h_old.emb.clone()       # (tables are plain attributes: not deep-copied)
         model.set_partition_context(ctx)
-        D.reserve_halo_tails(model, subs)
+        D.reserve_halo_tails(model, subs, regions=2)
         model.train()
         return model, torch.optim.SGD(model.parameters(), lr=0.05)
 
@@ -165,9 +170,12 @@ def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
         opt.zero_grad(set_to_none=False)
         torch.nn.functional.cross_entropy(out, y).backward()
 
+    pipe = D.HaloPipeline(model, [inp[0][1] for inp in prepared_inputs], ahead=ahead)
+    assert pipe.ahead == ahead
+    assert [s.data.adj_t._halo_plan.region for s in subs] == ([0, 1] if ahead else [0, 0])
+
     def step(k, replay):
-        for pending in model.start_halo_exchanges(prepared_inputs[k][0][1]):
-            pending.wait()
+        pipe.ready(k)
         graphs.replay(k) if replay else body(k)
         D.allreduce_flat_gradients(flat, ctx)
         opt.step()
@@ -179,6 +187,7 @@ def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
         graphs.warm(lambda: step(k, replay=False), times=1)
     # (a condition, not a pause: every collective issued so far is marked retired in
     # torch.distributed's own record before the recording starts)
+    pipe.drain()
     assert D.quiesce_collectives() == "retired"
     for k in range(len(subs)):
         graphs.capture(k, lambda: body(k), capture_error_mode="thread_local")
@@ -188,6 +197,7 @@ def test_recorded_step_between_eager_collectives_trains_like_eager_steps(rccl):
         h.emb_with_tail.copy_(t)
     for k in steps:
         step(k, replay=True)
+    pipe.drain()
     torch.cuda.synchronize()
     for (name, p), q in zip(model.named_parameters(), eager.parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(),
@@ -246,3 +256,20 @@ def test_two_ranks_over_rccl_match_single_process(mode, tmp_path):
         if mode == "in_place":
             assert res["gcn2/calls"]["in_place"] > 0 and res["gcn2/calls"]["buffer"] == 0
     check_against_single_process(ranks, 2, dev=torch.device("cuda", 0))
+
+
+def test_one_rank_exchange_one_step_ahead_over_rccl(tmp_path):
+    """The look-ahead exchange (distributed.HaloPipeline: seven batches, three tail regions) as
+    ONE fresh process on GPU 0 with the collectives forced on: every step's all-to-all calls
+    are issued while the step before still computes."""
+    from test_distributed_cpu import check_pipeline_against_single_process
+    ranks = _run_gpu_ranks(1, "pipeline", tmp_path)
+    assert ranks[0]["ahead"] and sorted(set(ranks[0]["regions"])) == [0, 1, 2]
+    check_pipeline_against_single_process(ranks, 1, dev=torch.device("cuda", 0))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_two_ranks_exchange_one_step_ahead_over_rccl(tmp_path):
+    from test_distributed_cpu import check_pipeline_against_single_process
+    ranks = _run_gpu_ranks(2, "pipeline", tmp_path)
+    check_pipeline_against_single_process(ranks, 2, dev=torch.device("cuda", 0))
