@@ -1,4 +1,4 @@
-"""The BASELINE configurations other than the headline one, through the training driver at full
+"""The BASELINE.json configurations other than the headline one, through the training driver at full
 (synthetic) size on one MI355X: GCN / ogbn-arxiv-sized, APPNP / reddit-sized, GraphSAGE /
 ogbn-products-sized with host-pinned History tables behind the staging pools."""
 import logging, os, sys, json, time

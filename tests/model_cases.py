@@ -33,7 +33,7 @@ MODEL_CASES = {
 }
 
 # The shape the headline metric is quoted on (GCNII, 8 layers x 256, a weight pair per layer, no
-# dropout: conf/model/gcn2.yaml:51-71 widened as BASELINE names it) on a 20k-node graph with the
+# dropout: conf/model/gcn2.yaml:51-71 widened to the 8 layers x 256 of BASELINE.json's headline configuration) on a 20k-node graph with the
 # input width and class count of ogbn-products: the [B,256]x[256,8*256] x_0 GEMM, the 8-slab
 # weight gradients and the side-by-side gradient blocks only exist at this depth and width.
 HEADLINE_CASES = {

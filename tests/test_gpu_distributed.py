@@ -2,7 +2,7 @@
 collectives issued although they move nothing): process-group set-up on the GPU, halo plans,
 `all_to_all_single` on device tensors, stream ordering of the pending exchange, the flat gradient
 all-reduce -- against the unsharded run of the same model.  Tables in HBM and in pinned host
-memory (BASELINE configuration 5's placement)."""
+memory (the placement of BASELINE.json's host-offload configuration)."""
 import os
 import socket
 import subprocess
