@@ -122,8 +122,15 @@ def device_partition_batch(data: Data, ptr: Tensor, part_ids, device,
     count = ptr[batch_id + 1] - offset
     idx = torch.cat([torch.arange(int(ptr[p]), int(ptr[p + 1]), device=device) for p in part_ids])
     rowptr, col, value = _device_graph(data.adj_t, device)
+    # the batch's rows are whole partitions, i.e. ranges of the global CSR: their edge count (the
+    # capacity of the output) comes from the host copy of the row pointers -- no device pass, no wait
+    bound, host_rowptr = None, data.adj_t.csr()[0]
+    if not host_rowptr.is_cuda:
+        bound = int(sum(int(host_rowptr[int(ptr[p + 1])]) - int(host_rowptr[int(ptr[p])])
+                        for p in part_ids))
     rp32, c32, val, n_id, _ = ops.relabel_one_hop_device(rowptr, col, value, idx,
-                                                         within_batch=in_batch_only)
+                                                         within_batch=in_batch_only,
+                                                         edge_capacity=bound)
     batch_size = idx.numel()
     adj_t = SparseTensor.from_device_csr(rp32, c32, val, (batch_size, n_id.numel()))
     out = data.__class__(adj_t=adj_t)

@@ -520,8 +520,9 @@ int incagg_partition_refine(const int64_t *rowptr, const int64_t *col, int64_t n
  *     entry; they are -1 again when the call returns (map_b may be NULL for within_batch)
  *   scratch: device bytes, at least incagg_relabel_device_scratch_bytes(n_idx, edge_capacity)
  *   edge_capacity / node_capacity: sizes of out_col / out_value and of out_n_id;
- *     incagg_relabel_bound_device gives the exact edge count of the full relabelling (an upper
- *     bound for within_batch); n_idx + that bound always suffices for the nodes
+ *     incagg_relabel_bound_device gives the exact edge count of the full relabelling, which is
+ *     the capacity BOTH variants need (within_batch writes fewer edges, but its work arrays hold
+ *     one entry per edge of the batch rows); n_idx + that bound always suffices for the nodes
  *   counts (HOST int64[3]): edges written, nodes in n_id, distinct ids in idx
  * Both calls enqueue on `stream` and then wait for it (the sizes come back to the host).
  */

@@ -27,7 +27,7 @@ for in_batch_only in (False, True):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sub = device_partition_batch(d, data.ptr, [p], dev, in_batch_only=in_batch_only)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        sub.data.adj_t.device_csr_t("sum"); sub.data.adj_t.row_order(); torch.cuda.synchronize()
+        sub.data.adj_t.device_csr_t("sum"); sub.data.adj_t.plan(); torch.cuda.synchronize()
         t2 = time.perf_counter()
         t_d.append((t1 - t0, t2 - t1))
     med = lambda xs: sorted(xs)[len(xs) // 2] * 1e3
