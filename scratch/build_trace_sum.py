@@ -7,7 +7,12 @@ names = [r["Kernel_Name"] for r in rows]
 first = [i for i, n in enumerate(names) if "incagg" in n][0]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in rows[first:]:
-    n = r["Kernel_Name"][:90]
+    n = r["Kernel_Name"]
+    if "rocprim" in n:      # which primitive, which key / value types
+        import re
+        m = re.search(r"detail::(\w+)<", n[60:])
+        n = "rocprim " + (m.group(1) if m else "?") + " | " + n[-110:]
+    n = n[:150]
     agg[n][0] += 1
     agg[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(v[1] for v in agg.values())
