@@ -41,6 +41,12 @@ SIGNATURES = {
     "incagg_tn_finish_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "incagg_tn_finish_batched_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "incagg_relu_rows_f32": (_int, [_vp, _i64, _i64, _i64, _vp]),
+    "incagg_batch_norm_supported": (_int, [_i64, _i64]),
+    "incagg_batch_norm_ws_floats": (_i64, [_i64, _i64]),
+    "incagg_batch_norm_forward_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp,
+                                             _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "incagg_batch_norm_backward_f32": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
+                                              _i64, _vp, _vp, _vp, _i64, _vp]),
     "incagg_rows_gemm_supported": (_int, [_i64, _i64]),
     "incagg_rows_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _i64, _i64, _int, _vp,
                                     _i64, _vp, _i64, _i64, _i64, _int, _int, _vp]),
@@ -86,7 +92,7 @@ class SpmmFuseStruct(_c.Structure):
 
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class AdamSegment(_c.Structure):

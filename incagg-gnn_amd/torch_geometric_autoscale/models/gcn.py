@@ -5,7 +5,7 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import BatchNorm1d, ModuleList
 
-from ..nn import GCNConv, RowsLinear, relu_into
+from ..nn import GCNConv, RowsLinear, batch_norm_rows, relu_into
 from .base import ScalableGNN
 
 
@@ -106,7 +106,7 @@ class GCN(ScalableGNN):
         h = self._conv_update(layer, agg, x, pre, push)
         if layer < self.num_layers - 1 or self.linear:
             if self.batch_norm:
-                h = self.bns[layer](h)
+                h = batch_norm_rows(self.bns[layer], h)
             if self.residual and h.size(-1) == x.size(-1):
                 h = h + (x if x.size(0) == h.size(0) else x[:h.size(0)])
             if state.get('defer_relu') and not self.linear:

@@ -8,7 +8,7 @@ from torch.nn import BatchNorm1d, ModuleList
 import torch
 
 from .. import ops
-from ..nn import GCN2Conv, RowsLinear, embed_relu, gcn2_batched_terms, relu_into
+from ..nn import GCN2Conv, RowsLinear, batch_norm_rows, embed_relu, gcn2_batched_terms, relu_into
 from .base import ScalableGNN
 
 
@@ -89,7 +89,7 @@ class GCN2(ScalableGNN):
 
     def _post(self, layer: int, h: Tensor, x: Tensor, state: Dict[str, Any] = None) -> Tensor:
         if self.batch_norm:
-            h = self.bns[layer](h)
+            h = batch_norm_rows(self.bns[layer], h)
         if self.residual and h.size(-1) == x.size(-1):
             h = h + (x if x.size(0) == h.size(0) else x[:h.size(0)])
         if state is not None and state.get('defer_relu') and layer < self.num_layers - 1:

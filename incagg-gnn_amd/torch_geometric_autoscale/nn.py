@@ -315,6 +315,43 @@ class _TwoTermUpdate(torch.autograd.Function):
         return dh, dw1, dx0, dw2, dterm, None, None
 
 
+class _BatchNormRows(torch.autograd.Function):
+    """Training-mode ``BatchNorm1d`` over the rows of a tall matrix as streaming row passes
+    (ops.batch_norm_forward / _backward); the input gradient overwrites the incoming gradient
+    when that is a private matrix of the right layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        y, mean, rstd = ops.batch_norm_forward(x, weight, bias, running_mean, running_var,
+                                               momentum, eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.mark_non_differentiable(mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        if not ops.batch_norm_supported(dy):     # (an expanded or oddly strided gradient)
+            dy = ops.rows_empty(dy.size(0), dy.size(1), dy.device).copy_(dy)
+        dx, dweight, dbias = ops.batch_norm_backward(dy, x, weight, mean, rstd)
+        return (dx if ctx.needs_input_grad[0] else None,
+                dweight if weight is not None and ctx.needs_input_grad[1] else None,
+                dbias if ctx.needs_input_grad[2] else None, None, None, None, None)
+
+
+def batch_norm_rows(bn: torch.nn.BatchNorm1d, h: Tensor) -> Tensor:
+    """``bn(h)``.  In training mode on a float32 device matrix this runs the package's streaming
+    row kernels (torch's own kernel walks down the columns of the row-major matrix: 13 ms for the
+    backward pass of a 169k x 256 matrix on MI355X against 0.2 ms); everything else -- evaluation
+    mode, cumulative averaging (``momentum=None``), unsupported layouts -- goes to the module."""
+    if (bn.training and bn.momentum is not None and bn.track_running_stats
+            and ops.batch_norm_supported(h) and (bn.weight is None or bn.weight.is_cuda)):
+        bn.num_batches_tracked.add_(1)
+        return _BatchNormRows.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                    float(bn.momentum), float(bn.eps))
+    return bn(h)
+
+
 class _Layers(torch.autograd.Function):
     """``stack.unbind(0)`` whose backward takes the gradients of the pieces where they are when
     their producers wrote them into ``grad_stack`` (a ``[L, ...]`` matrix, piece l in

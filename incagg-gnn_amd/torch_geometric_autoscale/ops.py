@@ -596,6 +596,69 @@ def column_sums(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def batch_norm_supported(x: Tensor) -> bool:
+    """Whether :func:`batch_norm_forward` takes ``x``: a float32 device matrix of at least two
+    rows whose width is a multiple of 4 and whose rows start 16-byte aligned."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) > 0
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and bool(lib().incagg_batch_norm_supported(x.size(0), x.size(1))))
+
+
+def _bn_workspace(x: Tensor) -> Tensor:
+    need = lib().incagg_batch_norm_ws_floats(x.size(0), x.size(1))
+    check(need)
+    return torch.empty(max(int(need), 4), dtype=torch.float32, device=x.device)
+
+
+def batch_norm_forward(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor],
+                       running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                       momentum: float, eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """Training-mode batch normalisation over the rows of ``x`` (incagg_batch_norm_forward_f32):
+    ``(y, mean, rstd)``; the running statistics are updated in place.  ``y`` has the row pitch
+    the aggregation kernels want."""
+    _need_cuda(x, "x")
+    if not batch_norm_supported(x):
+        raise ValueError("batch_norm_forward needs a float32 [rows >= 2, width % 4 == 0] matrix "
+                         "with 16-byte aligned rows")
+    rows, width = x.shape
+    for t, name in ((weight, "weight"), (bias, "bias"), (running_mean, "running_mean"),
+                    (running_var, "running_var")):
+        if t is not None and (t.shape != (width,) or t.dtype != torch.float32
+                              or t.device != x.device or not t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous [width] float32 tensor on the device of x")
+    y = rows_empty(rows, width, x.device)
+    stats = torch.empty((2, -(-width // 4) * 4), dtype=torch.float32, device=x.device)
+    ws = _bn_workspace(x)
+    with _on_device(x.device):
+        check(lib().incagg_batch_norm_forward_f32(
+            _ptr(x), _ld(x), rows, width, _ptr(weight), _ptr(bias), float(eps), float(momentum),
+            _ptr(running_mean), _ptr(running_var), _ptr(ws), ws.numel(), _ptr(stats[0]),
+            _ptr(stats[1]), _ptr(y), _ld(y), _stream_of(x.device)))
+    return y, stats[0], stats[1]
+
+
+def batch_norm_backward(dy: Tensor, x: Tensor, weight: Optional[Tensor], mean: Tensor, rstd: Tensor,
+                        dx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """``(dx, dweight, dbias)`` of :func:`batch_norm_forward` (incagg_batch_norm_backward_f32).
+    ``dx``: where to write (may be ``dy`` itself); default a fresh matrix at the gather pitch."""
+    _need_cuda(dy, "dy")
+    rows, width = x.shape
+    if dy.shape != x.shape or not batch_norm_supported(dy) or not batch_norm_supported(x):
+        raise ValueError("dy and x must be float32 [rows, width] matrices with 16-byte aligned rows")
+    if dx is None:
+        dx = rows_empty(rows, width, x.device)
+    elif dx.shape != x.shape or not batch_norm_supported(dx):
+        raise ValueError("dx must be a float32 [rows, width] matrix with 16-byte aligned rows")
+    grads = torch.empty((2, -(-width // 4) * 4), dtype=torch.float32, device=x.device)
+    ws = _bn_workspace(x)
+    with _on_device(x.device):
+        check(lib().incagg_batch_norm_backward_f32(
+            _ptr(dy), _ld(dy), _ptr(x), _ld(x), rows, width, _ptr(weight), _ptr(mean), _ptr(rstd),
+            _ptr(ws), ws.numel(), _ptr(grads[0]), _ptr(grads[1]), _ptr(dx), _ld(dx),
+            _stream_of(x.device)))
+    return dx, grads[0], grads[1]
+
+
 class _SoftmaxXent(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels):

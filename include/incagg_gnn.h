@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INCAGG_ABI_VERSION 6
+#define INCAGG_ABI_VERSION 7
 
 enum {
   INCAGG_OK = 0,
@@ -275,6 +275,31 @@ int incagg_tn_finish_batched_f32(const float *const *parts, int64_t n_batch, int
 int64_t incagg_column_sums_ws_floats(int64_t rows, int64_t width);
 int incagg_column_sums_f32(const float *x, int64_t ldx, int64_t rows, int64_t width, float *ws,
                            int64_t ws_floats, float *out, void *stream);
+
+/* torch.nn.BatchNorm1d in training mode on a tall row-major matrix [rows, width] (the layer
+ * outputs of a batch: models/gcn.py:145,181,248, models/gcn2.py:132,161,267,
+ * models/graphsage.py:191), as streaming passes over rows as they lie in memory:
+ *   forward : mean[c], rstd[c] = 1 / sqrt(biased var + eps) of the batch are written out (the
+ *             backward pass needs them), y = (x - mean) rstd gamma + beta (gamma / beta may be
+ *             NULL: 1 / 0), running_mean / running_var (may be NULL) move by `momentum` towards
+ *             the batch mean / the unbiased batch variance, as the module does;
+ *   backward: dbeta = sum_r dy, dgamma = sum_r dy xhat, dx = gamma rstd (dy - dbeta / rows -
+ *             xhat dgamma / rows) with xhat = (x - mean) rstd; dx may be dy's memory.
+ * rows >= 2, width a multiple of 4 (incagg_batch_norm_supported); rows of x, y, dy, dx and all
+ * per-column arrays 16-byte aligned; ws: device fp32 scratch of >=
+ * incagg_batch_norm_ws_floats(rows, width).  Fixed summation order. */
+int incagg_batch_norm_supported(int64_t rows, int64_t width);
+int64_t incagg_batch_norm_ws_floats(int64_t rows, int64_t width);
+int incagg_batch_norm_forward_f32(const float *x, int64_t ldx, int64_t rows, int64_t width,
+                                  const float *gamma, const float *beta, float eps, float momentum,
+                                  float *running_mean, float *running_var, float *ws,
+                                  int64_t ws_floats, float *mean, float *rstd, float *y,
+                                  int64_t ldy, void *stream);
+int incagg_batch_norm_backward_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx,
+                                   int64_t rows, int64_t width, const float *gamma,
+                                   const float *mean, const float *rstd, float *ws,
+                                   int64_t ws_floats, float *dgamma, float *dbeta, float *dx,
+                                   int64_t lddx, void *stream);
 
 /* Mean softmax cross entropy of logits [rows, classes] (ld) against int64 class labels -- the
  * value of torch.nn.CrossEntropyLoss() with its defaults (main.py:60,78) -- and its gradient:

@@ -276,3 +276,100 @@ def test_rows_gemm_matches_float64(rows, k, n, trans_w):
     with pytest.raises(Exception):
         ops.rows_gemm(xbuf[:, :k - 1], w[:, :k - 1] if trans_w else w[:k - 1], trans_w)
     _lib.check_device_errors()
+
+
+@pytest.mark.parametrize("rows,width,pitch", [(16326, 256, 260), (5000, 40, 40), (2, 4, 4),
+                                              (70001, 128, 132), (333, 1028, 1028)])
+def test_batch_norm_rows_matches_float64(ops, rows, width, pitch):
+    """Training-mode batch norm over rows (incagg_batch_norm_forward_f32 / _backward_f32) against
+    torch's batch_norm on float64 copies: output, saved statistics, running statistics, and the
+    three gradients; columns with a mean far from zero (the shifted moments must not cancel)."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(rows + width)
+    x64 = torch.randn(rows, width, generator=g, dtype=torch.float64)
+    x64 = x64 * torch.linspace(0.1, 3.0, width, dtype=torch.float64) \
+        + torch.linspace(-50.0, 200.0, width, dtype=torch.float64)
+    w64 = torch.rand(width, generator=g, dtype=torch.float64) + 0.5
+    b64 = torch.randn(width, generator=g, dtype=torch.float64)
+    dy64 = torch.randn(rows, width, generator=g, dtype=torch.float64)
+    rm64 = torch.randn(width, generator=g, dtype=torch.float64)
+    rv64 = torch.rand(width, generator=g, dtype=torch.float64) + 0.5
+    momentum, eps = 0.1, 1e-5
+    # (the float64 side works on the values the kernels get: rounded to float32)
+    x64, w64, b64, dy64, rm64, rv64 = (t.float().double() for t in (x64, w64, b64, dy64, rm64, rv64))
+
+    xr = x64.clone().requires_grad_(True)
+    wr, br = w64.clone().requires_grad_(True), b64.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm64.clone(), rv64.clone()
+    want = torch.nn.functional.batch_norm(xr, rm_ref, rv_ref, wr, br, True, momentum, eps)
+    want.backward(dy64)
+
+    buf = torch.zeros(rows, pitch, device=dev)
+    x = buf[:, :width]
+    x.copy_(x64)
+    dybuf = torch.zeros(rows, pitch, device=dev)
+    dy = dybuf[:, :width]
+    dy.copy_(dy64)
+    w, b = w64.float().to(dev), b64.float().to(dev)
+    rm, rv = rm64.float().to(dev), rv64.float().to(dev)
+    assert ops.batch_norm_supported(x)
+    y, mean, rstd = ops.batch_norm_forward(x, w, b, rm, rv, momentum, eps)
+    scale = float(want.detach().abs().max())
+    assert float((y.double().cpu() - want.detach()).abs().max()) <= 2e-5 * max(scale, 1.0)
+    np.testing.assert_allclose(mean[:width].cpu().numpy(), x64.mean(0).numpy(), rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(rstd[:width].cpu().numpy(),
+                               (1.0 / torch.sqrt(x64.var(0, unbiased=False) + eps)).numpy(),
+                               rtol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv_ref.numpy(), rtol=2e-5, atol=1e-6)
+    dx, dw, db = ops.batch_norm_backward(dy, x, w, mean, rstd)
+    tol = 2e-5 * max(float(xr.grad.abs().max()), 1e-3) + 1e-6
+    assert float((dx.double().cpu() - xr.grad).abs().max()) <= tol + 2e-4 * float(xr.grad.abs().max())
+    np.testing.assert_allclose(dw[:width].cpu().numpy(), wr.grad.numpy(), rtol=2e-4,
+                               atol=2e-4 * float(wr.grad.abs().max()))
+    np.testing.assert_allclose(db[:width].cpu().numpy(), br.grad.numpy(), rtol=2e-4,
+                               atol=2e-4 * float(br.grad.abs().max()))
+    # in place over the incoming gradient
+    dx2, _, _ = ops.batch_norm_backward(dy, x, w, mean, rstd, dx=dy)
+    assert dx2.data_ptr() == dy.data_ptr() and torch.equal(dx2, dx)
+    # without affine parameters and without running statistics
+    y0, m0, r0 = ops.batch_norm_forward(x, None, None, None, None, momentum, eps)
+    want0 = torch.nn.functional.batch_norm(x64, None, None, None, None, True, momentum, eps)
+    assert float((y0.double().cpu() - want0).abs().max()) <= 2e-5 * max(float(want0.abs().max()), 1.0)
+    from torch_geometric_autoscale import _lib
+    _lib.check_device_errors()
+
+
+def test_batch_norm_rows_module_path_and_errors(ops):
+    """nn.batch_norm_rows takes the kernel path in training mode (same result as the module, the
+    module's buffers updated, gradients through autograd) and the module itself in evaluation
+    mode; unsupported layouts are refused by the entry point."""
+    from torch_geometric_autoscale import nn as tnn
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(64).to(dev)
+    ref = torch.nn.BatchNorm1d(64).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    ref.load_state_dict(bn.state_dict())
+    x = torch.randn(3000, 64, device=dev) * 2 + 1
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = tnn.batch_norm_rows(bn, xa), ref(xb)
+    assert float((ya - yb).detach().abs().max()) <= 1e-4
+    go = torch.randn_like(ya)
+    ya.backward(go)
+    yb.backward(go)
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-4 * float(xb.grad.abs().max()) + 1e-6
+    assert float((bn.weight.grad - ref.weight.grad).abs().max()) <= 1e-3 * float(ref.weight.grad.abs().max())
+    assert float((bn.bias.grad - ref.bias.grad).abs().max()) <= 1e-3 * float(ref.bias.grad.abs().max())
+    assert int(bn.num_batches_tracked) == 1
+    assert float((bn.running_mean - ref.running_mean).abs().max()) <= 1e-5
+    assert float((bn.running_var - ref.running_var).abs().max()) <= 1e-4
+    bn.eval()
+    ref.eval()
+    assert torch.equal(tnn.batch_norm_rows(bn, x), bn(x))
+    with pytest.raises(ValueError):
+        ops.batch_norm_forward(torch.randn(10, 6, device=dev), None, None, None, None, 0.1, 1e-5)
+    with pytest.raises(ValueError):
+        ops.batch_norm_forward(torch.randn(1, 8, device=dev), None, None, None, None, 0.1, 1e-5)
