@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const float *u, long long 
                   (p.w + q.w) + (s.w + t.w));
 }
 
-// One thread per column adds the partial rows up in double.
+// Adds the partial rows up in double: 16 threads share a column (thread g of them takes partial
+// rows g, g + 16, ...) and meet in LDS; a workgroup covers 16 columns.
 // MOMENTS: mean / rstd out, running statistics updated; otherwise dbeta / dgamma out.
 template <bool MOMENTS>
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float *part, int n_part, int width,
@@ -105,12 +106,24 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float *part, int n
                                                         float momentum, float *running_mean,
                                                         float *running_var, float *out_a,
                                                         float *out_b) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= width) return;
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double sa = 0.0, sb = 0.0;
-  for (int p = 0; p < n_part; p++) {
-    sa += (double)part[(long long)(2 * p) * width + c];
-    sb += (double)part[(long long)(2 * p + 1) * width + c];
+  if (c < width) {
+    for (int p = g; p < n_part; p += 16) {
+      sa += (double)part[(long long)(2 * p) * width + c];
+      sb += (double)part[(long long)(2 * p + 1) * width + c];
+    }
+  }
+  red[0][g][cl] = sa;
+  red[1][g][cl] = sb;
+  __syncthreads();
+  if (g != 0 || c >= width) return;
+  sa = sb = 0.0;
+  for (int k = 0; k < 16; k++) {   // fixed order
+    sa += red[0][k][cl];
+    sb += red[1][k][cl];
   }
   if (!MOMENTS) {
     out_a[c] = (float)sa;   // dbeta
@@ -220,7 +233,7 @@ extern "C" int incagg_batch_norm_forward_f32(const float *x, int64_t ldx, int64_
   hipLaunchKernelGGL(bn_sums_kernel<true>, dim3((unsigned)n_part, col_blocks), dim3(256), 0, stream,
                      (const float *)nullptr, 0ll, x, (long long)ldx, (int)rows, (int)width, rpb,
                      (const float *)nullptr, (const float *)nullptr, ws);
-  hipLaunchKernelGGL(bn_finish_kernel<true>, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bn_finish_kernel<true>, dim3((unsigned)((width + 15) / 16)), dim3(256), 0, stream,
                      ws, n_part, (int)width, (int)rows, x, eps, momentum, running_mean, running_var,
                      mean, rstd);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_stream_grid(rows * (width / 4))), dim3(256), 0, stream, x,
@@ -254,7 +267,7 @@ extern "C" int incagg_batch_norm_backward_f32(const float *dy, int64_t lddy, con
   const unsigned col_blocks = (unsigned)((width + kBnCols - 1) / kBnCols);
   hipLaunchKernelGGL(bn_sums_kernel<false>, dim3((unsigned)n_part, col_blocks), dim3(256), 0, stream, dy,
                      (long long)lddy, x, (long long)ldx, (int)rows, (int)width, rpb, mean, rstd, ws);
-  hipLaunchKernelGGL(bn_finish_kernel<false>, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bn_finish_kernel<false>, dim3((unsigned)((width + 15) / 16)), dim3(256), 0, stream,
                      ws, n_part, (int)width, (int)rows, (const float *)nullptr, 0.f, 0.f,
                      (float *)nullptr, (float *)nullptr, dbeta, dgamma);
   hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(bn_stream_grid(rows * (width / 4))), dim3(256), 0,
