@@ -137,8 +137,8 @@ class History(torch.nn.Module):
         dev = self._device if self._device.type == "cuda" else self.emb.device
         if dev.type != "cuda":
             return torch.cat([self.emb[o:o + c] for o, c in zip(offset.tolist(), count.tolist())])
-        if out is None:
-            out = torch.empty((total, self.embedding_dim), dtype=self.emb.dtype, device=dev)
+        if out is None:     # at the row pitch the aggregation kernels want for their operands
+            out = ops.rows_empty(total, self.embedding_dim, dev, self.emb.dtype)
         ops.copy_row_chunks(out, self.emb, offset, count, packed_is_src=False, device=dev)
         return out[:total]
 
