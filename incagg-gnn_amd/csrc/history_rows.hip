@@ -104,15 +104,35 @@ __global__ __launch_bounds__(256) void chunk_rows_kernel(float *dst, long long l
     }
     for (int col = lane * VEC; col < dst_width; col += 64 * VEC) {
       V v[kRowsInFlight];
+      // VEC == 4: rows start 16-byte aligned on both sides; widths need not be multiples of 4
+      // (41- and 47-wide tables): the quad that straddles the end of a row goes element by element
+      const bool whole_src = VEC == 1 || col + VEC <= src_width;
+      const bool whole_dst = VEC == 1 || col + VEC <= dst_width;
 #pragma unroll
       for (int u = 0; u < kRowsInFlight; u++) {
         v[u] = V(0.f);
-        if (ok[u] && col < src_width) v[u] = *reinterpret_cast<const V *>(s[u] + col);
+        if (ok[u]) {
+          if (whole_src) {
+            v[u] = *reinterpret_cast<const V *>(s[u] + col);
+          } else if constexpr (VEC == 4) {
+            if (col < src_width) v[u].x = s[u][col];
+            if (col + 1 < src_width) v[u].y = s[u][col + 1];
+            if (col + 2 < src_width) v[u].z = s[u][col + 2];
+          }
+        }
         if (relu) v[u] = relu_of(v[u]);
       }
 #pragma unroll
-      for (int u = 0; u < kRowsInFlight; u++)
-        if (ok[u]) *reinterpret_cast<V *>(d[u] + col) = v[u];
+      for (int u = 0; u < kRowsInFlight; u++) {
+        if (!ok[u]) continue;
+        if (whole_dst) {
+          *reinterpret_cast<V *>(d[u] + col) = v[u];
+        } else if constexpr (VEC == 4) {
+          d[u][col] = v[u].x;
+          if (col + 1 < dst_width) d[u][col + 1] = v[u].y;
+          if (col + 2 < dst_width) d[u][col + 2] = v[u].z;
+        }
+      }
     }
   }
 }
@@ -195,8 +215,7 @@ extern "C" int incagg_copy_row_chunks_f32(float *dst, int64_t ldd, int64_t dst_r
   if (total > packed_rows)
     return fail(INCAGG_E_INDEX, "Invalid index: chunks hold %lld rows, packed side has %lld",
                 (long long)total, (long long)packed_rows);
-  const bool vec4 = dst_width % 4 == 0 && src_width % 4 == 0 && aligned16(dst) && aligned16(src) &&
-                    ldd % 4 == 0 && lds % 4 == 0;
+  const bool vec4 = aligned16(dst) && aligned16(src) && ldd % 4 == 0 && lds % 4 == 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int64_t packed_row = 0;
   for (int64_t c0 = 0; c0 < n_chunks; c0 += kMaxChunks) {
