@@ -68,7 +68,7 @@ __device__ __forceinline__ f4 relu_of(f4 v) {
   return r;
 }
 
-constexpr int kMaxChunks = 32;
+constexpr int kMaxChunks = 64;   // (one boundary per lane of a wave: see chunk_rows_kernel)
 
 struct ChunkTable {
   long long dst_row[kMaxChunks];
@@ -88,6 +88,10 @@ __global__ __launch_bounds__(256) void chunk_rows_kernel(float *dst, long long l
   const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6);
   const long long n_waves = gridDim.x * 4ll;
   const long long total = t.first[t.n];
+  // lane l keeps the first row of chunk l + 1: the chunk of a row is then the number of lanes
+  // whose boundary it has reached -- one compare and a ballot instead of a walk through the
+  // table (up to 32 dependent scalar loads per row: 31 us per launch over 100 partitions)
+  const long long boundary = lane + 1 < t.n ? t.first[lane + 1] : LLONG_MAX;
   for (long long r0 = wave; r0 < total; r0 += n_waves * kRowsInFlight) {
     const float *s[kRowsInFlight];
     float *d[kRowsInFlight];
@@ -96,8 +100,7 @@ __global__ __launch_bounds__(256) void chunk_rows_kernel(float *dst, long long l
     for (int u = 0; u < kRowsInFlight; u++) {
       const long long r = r0 + u * n_waves;
       ok[u] = r < total;
-      int c = 0;
-      while (ok[u] && c + 1 < t.n && r >= t.first[c + 1]) c++;
+      const int c = ok[u] ? __popcll(__ballot(r >= boundary)) : 0;
       const long long i = ok[u] ? r - t.first[c] : 0;
       s[u] = src + (t.src_row[c] + i) * lds;
       d[u] = dst + (t.dst_row[c] + i) * ldd;

@@ -120,7 +120,12 @@ def device_partition_batch(data: Data, ptr: Tensor, part_ids, device,
     batch_id = torch.tensor(part_ids)
     offset = ptr[batch_id]
     count = ptr[batch_id + 1] - offset
-    idx = torch.cat([torch.arange(int(ptr[p]), int(ptr[p + 1]), device=device) for p in part_ids])
+    # the node ids of the partitions, one after another, in three device operations (an arange
+    # per partition costs a launch each: 100 of them for a reddit-sized batch)
+    total = int(count.sum())
+    first = (offset - (count.cumsum(0) - count)).to(device)
+    idx = torch.repeat_interleave(first, count.to(device), output_size=total) \
+        + torch.arange(total, device=device)
     rowptr, col, value = _device_graph(data.adj_t, device)
     # the batch's rows are whole partitions, i.e. ranges of the global CSR: their edge count (the
     # capacity of the output) comes from the host copy of the row pointers -- no device pass, no wait
