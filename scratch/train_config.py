@@ -18,6 +18,20 @@ CONFIGS = {
                                                        dropout=0.3),
                                      num_parts=200, pool_size=2, lr=0.01, grad_norm=1.0, epochs=4,
                                      **common)),
+    # conf/model/gcn2.yaml: arxiv (shared weights, batch norm) and reddit (drop_input, batch norm)
+    "gcn2_arxiv": dict(dataset="arxiv", model="GCN2", batch_size=20, VR_update=True, params=dict(
+        architecture=dict(num_layers=4, hidden_channels=256, dropout=0.3, drop_input=False,
+                          batch_norm=True, residual=False, shared_weights=True, alpha=0.2, theta=0.5),
+        num_parts=80, pool_size=2, lr=0.01, grad_norm=None, epochs=4, **common)),
+    "gcn2_reddit": dict(dataset="reddit", model="GCN2", batch_size=100, VR_update=True, params=dict(
+        architecture=dict(num_layers=4, hidden_channels=256, dropout=0.5, drop_input=True,
+                          batch_norm=True, residual=False, shared_weights=False, alpha=0.1, theta=0.5),
+        num_parts=200, pool_size=2, lr=0.01, grad_norm=None, epochs=4, **common)),
+    # conf/model/graphsage.yaml: arxiv (batch norm)
+    "sage_arxiv": dict(dataset="arxiv", model="GraphSAGE", batch_size=40, VR_update=True, params=dict(
+        architecture=dict(num_layers=3, hidden_channels=256, dropout=0.5, drop_input=False,
+                          batch_norm=True, residual=False),
+        num_parts=80, pool_size=2, lr=0.01, grad_norm=None, epochs=4, **common)),
     "sage_products_host": dict(dataset="products", model="GraphSAGE", batch_size=1, VR_update=False,
                                history_device="host", params=dict(
         architecture=dict(num_layers=3, hidden_channels=256, dropout=0.3, drop_input=False,
