@@ -75,6 +75,9 @@ def parse():
                          "partitions; auto = only on a single GPU")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the partition-parallel code path even with one rank")
+    ap.add_argument("--batch-norm", action="store_true",
+                    help="GCN / GraphSAGE: batch norm after every layer but the last, as "
+                         "conf/model/gcn.yaml has it for ogbn-arxiv (the presets leave it out)")
     ap.add_argument("--halo-ahead", choices=["on", "off"], default="on",
                     help="partition-parallel push/pull steps: exchange the out-of-batch rows of the "
                          "next step's batch while the current step computes (off: at the top of "
@@ -456,11 +459,12 @@ def main():
                      shared_weights=False, dropout=0.0, device=table_dev, **pool)
     elif args.model == "gcn":
         model = GCN(table_rows, f_in, args.hidden, n_cls, args.layers, dropout=0.0,
-                    drop_input=False, batch_norm=False, residual=False, device=table_dev, **pool)
+                    drop_input=False, batch_norm=args.batch_norm, residual=False, device=table_dev,
+                    **pool)
     elif args.model == "sage":
         model = GraphSAGE(table_rows, f_in, args.hidden, n_cls, args.layers, dropout=0.0,
-                          drop_input=False, batch_norm=False, residual=False, device=table_dev,
-                          **pool)
+                          drop_input=False, batch_norm=args.batch_norm, residual=False,
+                          device=table_dev, **pool)
     else:
         model = APPNP(table_rows, f_in, args.hidden, n_cls, args.layers, alpha=0.1, dropout=0.0,
                       device=table_dev, **pool)
@@ -803,7 +807,9 @@ def main():
                 "workload": f"{MODEL_NAMES[args.model]} {args.layers}-layer hidden {args.hidden} on "
                             f"an ogbn-{args.dataset}-sized synthetic graph (N={n}, "
                             f"nnz={data.adj_t.nnz()}), {args.parts} partitions, {args.batch_parts} "
-                            f"per step, {args.mode} training step, History tables "
+                            f"per step, {args.mode} training step, "
+                            + ("batch norm after every hidden layer, " if args.batch_norm else "")
+                            + "History tables "
                             + ("in pinned host memory behind the staging pools" if host_tables
                                else "resident in HBM"),
                 "preset": args.config,

@@ -11,6 +11,8 @@ print('${name}', round(d['value']/1e9,3),'G edges/s', round(d['ms_per_step'],3),
 run products_gcn2_vr --mode vr --cpu-seconds 4 && \
 run arxiv_gcn --config arxiv-gcn --cpu-seconds 4 && \
 run arxiv_gcn_vr --config arxiv-gcn --mode vr --cpu-seconds 4 && \
+run arxiv_gcn_bn --config arxiv-gcn --batch-norm --cpu-seconds 4 && \
+run arxiv_gcn_bn_vr --config arxiv-gcn --batch-norm --mode vr --cpu-seconds 4 && \
 run reddit_appnp --config reddit-appnp --cpu-seconds 4 && \
 run reddit_appnp_vr --config reddit-appnp --mode vr --cpu-seconds 4 && \
 run products_sage_host --config products-sage-host --cpu-seconds 4 && \
