@@ -325,7 +325,6 @@ class _BatchNormRows(torch.autograd.Function):
         y, mean, rstd = ops.batch_norm_forward(x, weight, bias, running_mean, running_var,
                                                momentum, eps)
         ctx.save_for_backward(x, weight, mean, rstd)
-        ctx.mark_non_differentiable(mean, rstd)
         return y
 
     @staticmethod
