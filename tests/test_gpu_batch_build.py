@@ -105,6 +105,9 @@ def test_device_relabel_errors_and_edges(ops, dev):
     with pytest.raises(RuntimeError):       # capacity too small for the batch
         ops.relabel_one_hop_device(rowptr, col, None, torch.tensor([0, 1], device=dev),
                                    edge_capacity=1)
+    with pytest.raises(RuntimeError):       # ... also for the within-batch variant, whose work
+        ops.relabel_one_hop_device(rowptr, col, None, torch.tensor([0, 1], device=dev),   # arrays
+                                   within_batch=True, edge_capacity=1)     # hold every edge of the rows
     # after failed calls the tables are clean: a good call still gives the right answer
     rp, c, v, nid, _ = ops.relabel_one_hop_device(rowptr, col, None, torch.tensor([1], device=dev))
     assert rp.tolist() == [0, 1] and c.tolist() == [1] and nid.tolist() == [1, 0] and v is None
