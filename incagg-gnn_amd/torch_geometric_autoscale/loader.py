@@ -7,7 +7,6 @@ relabelling, ``data.x = x[n_id]``, ``offset`` / ``count`` the contiguous global 
 ranges of the batch's partitions.  The transposed CSR for the backward pass and the
 in-batch / halo split are derived once per batch object, never per training step.
 """
-import random
 import time
 from typing import List, NamedTuple, Tuple
 

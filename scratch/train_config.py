@@ -38,7 +38,9 @@ CONFIGS = {
                           batch_norm=False, residual=False),
         num_parts=150, pool_size=2, lr=0.005, grad_norm=None, epochs=2, **common)),
 }
-c = CONFIGS[which]
+c = dict(CONFIGS[which])
+if os.environ.get("GAS") == "1":     # the push/pull step instead of the incremental one
+    c["VR_update"] = False
 conf = {"seed": 0, "dataset": {"name": c["dataset"]}, "batch_size": c["batch_size"],
         "VR_update": c["VR_update"], "history_device": c.get("history_device", "model"),
         "synthetic_scale": float(os.environ.get("SCALE", "1.0")),

@@ -1,7 +1,6 @@
 """Partitioner stand-in (native BFS blocks + refinement) and the partition file formats."""
 from collections import deque
 
-import numpy as np
 import pytest
 import torch
 
