@@ -93,6 +93,25 @@ print(f"one launch {timeit(one):.1f} us | in-batch part {timeit(first):.1f} us |
       f"{timeit(second):.1f} us | both {timeit(two):.1f} us", flush=True)
 _lib.check_device_errors()
 
+# ---- does it help to have touched the table rows just before (they would then come from the
+# Infinity Cache instead of HBM)?  The touch is a gather of the batch's out-of-batch rows.
+oob_ids = sub.n_id.to(dev)[B:].contiguous()
+scratch_rows = ops.rows_empty(oob_ids.numel(), F, dev)
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(24)]
+for label, touch in (("cold", False), ("touched just before", True)):
+    for i in range(24):
+        k[0] += 1
+        tab = tables[k[0] % 6]
+        if touch:
+            ops.gather_rows(tab, oob_ids, out=scratch_rows)
+        ev[i][0].record()
+        ops.spmm_csr(rp, cip, v, xb, B + N, x_halo=tab, plan=plan, relu_x=True)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev[4:])
+    print(f"one launch, table rows {label}: {ts[len(ts) // 2] * 1e3:.1f} us (event interval)", flush=True)
+_lib.check_device_errors()
+
 # ---- the two parts as concurrent launches on two streams (no dependency between them): do
 # L2-served gathers and HBM-cold gathers overlap when they come from different waves?
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()

@@ -41,6 +41,8 @@ CONFIGS = {
 c = dict(CONFIGS[which])
 if os.environ.get("GAS") == "1":     # the push/pull step instead of the incremental one
     c["VR_update"] = False
+if os.environ.get("EPOCHS"):
+    c["params"] = dict(c["params"], epochs=int(os.environ["EPOCHS"]))
 conf = {"seed": 0, "dataset": {"name": c["dataset"]}, "batch_size": c["batch_size"],
         "VR_update": c["VR_update"], "history_device": c.get("history_device", "model"),
         "synthetic_scale": float(os.environ.get("SCALE", "1.0")),
