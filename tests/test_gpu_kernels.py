@@ -511,6 +511,40 @@ def test_chunk_copy_pads_with_zeros_and_many_chunks(ops, dev):
     assert np.array_equal(table.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("w_src,w_dst", [(41, 41), (41, 47), (37, 48), (3, 9), (47, 47), (5, 6)])
+def test_chunk_copy_odd_widths_on_aligned_rows(ops, dev, w_src, w_dst):
+    """Rows that start 16-byte aligned on both sides but whose widths are not multiples of 4: the
+    vector path with element-wise handling of the quad across each row end; columns past the
+    destination width (the row's padding) stay untouched."""
+    rng = np.random.default_rng(w_src * 64 + w_dst)
+    n, pitch = 700, 48
+    base = torch.full((n, pitch), 7.0, device=dev)
+    table = base[:, :w_dst]
+    offset = np.array([600, 0, 130, 300], dtype=np.int64)
+    count = np.array([100, 57, 0, 33], dtype=np.int64)
+    xb = torch.full((int(count.sum()), pitch), -5.0, device=dev)
+    x = rng.standard_normal((int(count.sum()), w_src)).astype(np.float32)
+    xb[:, :w_src] = torch.from_numpy(x).to(dev)
+    for relu in (False, True):
+        base.fill_(7.0)
+        ops.copy_row_chunks(table, xb[:, :w_src], torch.from_numpy(offset), torch.from_numpy(count),
+                            packed_is_src=True, relu=relu)
+        ref = np.full((n, pitch), 7.0, dtype=np.float32)
+        s = 0
+        for o, c in zip(offset, count):
+            ref[o:o + c, :w_src] = np.maximum(x[s:s + c], 0) if relu else x[s:s + c]
+            ref[o:o + c, w_src:w_dst] = 0
+            s += c
+        assert np.array_equal(base.cpu().numpy(), ref)
+    # and back out of the table (packed side is the destination)
+    out = torch.full((int(count.sum()), pitch), 9.0, device=dev)
+    ops.copy_row_chunks(out[:, :w_dst], table, torch.from_numpy(offset), torch.from_numpy(count),
+                        packed_is_src=False)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :w_src], np.maximum(x, 0))
+    assert np.all(got[:, w_dst:] == 9.0)
+
+
 def test_chunk_copy_rejects_bad_chunks(ops, dev):
     table = torch.zeros(10, 8, device=dev)
     x = torch.zeros(4, 8, device=dev)
