@@ -8,7 +8,8 @@ from torch.nn import BatchNorm1d, ModuleList
 import torch
 
 from .. import ops
-from ..nn import GCN2Conv, RowsLinear, batch_norm_rows, embed_relu, gcn2_batched_terms, relu_into
+from ..nn import (GCN2Conv, RowsLinear, batch_norm_rows, embed_relu, gcn2_batched_terms, relu_into,
+                  scaled_fan_out)
 from .base import ScalableGNN
 
 
@@ -85,6 +86,12 @@ class GCN2(ScalableGNN):
                                         for i in range(self.num_layers)]
             state['w1f'], state['x0_terms'], state['dw1'] = gcn2_batched_terms(
                 self.convs, state['x_0'], stack)
+        elif (self.convs[0].weight2 is None and torch.is_grad_enabled() and x.is_cuda
+              and x.dtype == torch.float32 and self.num_layers <= 16
+              and len({conv.alpha for conv in self.convs}) == 1):
+            # shared weights: alpha * x_0 computed once for all layers (it rides in every
+            # layer's aggregation epilogue), its gradient summed over the layers in one launch
+            state['x_0_mix'] = scaled_fan_out(state['x_0'], self.convs[0].alpha, self.num_layers)
         return F.dropout(x, p=self.dropout, training=self.training)
 
     def _post(self, layer: int, h: Tensor, x: Tensor, state: Dict[str, Any] = None) -> Tensor:
@@ -124,6 +131,9 @@ class GCN2(ScalableGNN):
         conv = self.convs[layer]
         if conv.weight2 is not None:
             return None
+        terms = state.get('x_0_mix')
+        if terms is not None:
+            return 1.0 - conv.alpha, terms[layer], 1.0
         return 1.0 - conv.alpha, state['x_0'], conv.alpha
 
     def _update_mixed(self, layer: int, mixed: Tensor, x: Tensor, state: Dict[str, Any]) -> Tensor:
