@@ -74,6 +74,18 @@ def pipeline_main(out_dir, dev, on_gpu):
                 ret = model(x, adj, b, sub.n_id, sub.offset, sub.count, halo_ready=True)
             result[f"step{i}"] = ret["out"].detach().clone()
         pipe.drain()
+        # two more steps on batch 0, back to back: the first after the drain (nothing in flight),
+        # the second with the look-ahead for batch 1 in flight, which is then dropped -- both
+        # exchange at the top of the step itself
+        for j in range(2):
+            sub = subs[0]
+            pipe.ready(0)
+            x = sub.data.x.to(dev) if on_gpu else sub.data.x
+            adj = sub.data.adj_t.to(dev) if on_gpu else sub.data.adj_t
+            with torch.no_grad():
+                ret = model(x, adj, sub.batch_size, sub.n_id, sub.offset, sub.count, halo_ready=True)
+            result[f"extra{j}"] = ret["out"].detach().clone()
+        pipe.drain()
         for i in range(1, model.num_layers):
             result[f"hist{i}"] = model.histories[i].emb.clone()
     if on_gpu:
