@@ -509,8 +509,9 @@ __global__ __launch_bounds__(256) void relu_rows_kernel(float *x, long long ld, 
   }
 }
 
-// dst += src wherever gate > 0 (the backward of a relu added onto an existing gradient).
-template <int VEC>
+// ADD: dst += src wherever gate > 0 (the backward of a relu added onto an existing gradient);
+// otherwise dst = src wherever gate > 0, else 0 (the backward of a relu; dst may be src).
+template <int VEC, bool ADD>
 __global__ __launch_bounds__(256) void gate_add_rows_kernel(float *dst, long long ldd,
                                                             const float *src, long long lds,
                                                             const float *gate, long long ldg,
@@ -524,7 +525,8 @@ __global__ __launch_bounds__(256) void gate_add_rows_kernel(float *dst, long lon
     float *d = dst + r * ldd + c;
     const float *s = src + r * lds + c, *g = gate + r * ldg + c;
     if (VEC == 4) {
-      float4 dv = *reinterpret_cast<float4 *>(d);
+      float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ADD) dv = *reinterpret_cast<float4 *>(d);
       const float4 sv = *reinterpret_cast<const float4 *>(s);
       const float4 gv = *reinterpret_cast<const float4 *>(g);
       dv.x += gv.x > 0.f ? sv.x : 0.f;
@@ -533,7 +535,8 @@ __global__ __launch_bounds__(256) void gate_add_rows_kernel(float *dst, long lon
       dv.w += gv.w > 0.f ? sv.w : 0.f;
       *reinterpret_cast<float4 *>(d) = dv;
     } else {
-      *d += *g > 0.f ? *s : 0.f;
+      const float v = *g > 0.f ? *s : 0.f;
+      *d = ADD ? *d + v : v;
     }
   }
 }
@@ -639,9 +642,8 @@ extern "C" int incagg_relu_rows_f32(float *x, int64_t ld, int64_t rows, int64_t 
   return INCAGG_OK;
 }
 
-extern "C" int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds,
-                                        const float *gate, int64_t ldg, int64_t rows, int64_t width,
-                                        void *stream) {
+static int gate_rows(bool add, float *dst, int64_t ldd, const float *src, int64_t lds,
+                     const float *gate, int64_t ldg, int64_t rows, int64_t width, void *stream) {
   INCAGG_REQUIRE(rows >= 0 && width >= 0 && width < INT_MAX, "bad size");
   if (rows == 0 || width == 0) return INCAGG_OK;
   INCAGG_REQUIRE(dst && src && gate && ldd >= width && lds >= width && ldg >= width,
@@ -651,14 +653,32 @@ extern "C" int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *sr
   const long long items = rows * (width / (vec ? 4 : 1));
   const int blocks = (int)std::min<long long>((items + 255) / 256, 8192);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (vec)
-    hipLaunchKernelGGL((gate_add_rows_kernel<4>), dim3(blocks), dim3(256), 0, s, dst, ldd, src, lds,
-                       gate, ldg, rows, (int)width);
+  if (vec && add)
+    hipLaunchKernelGGL((gate_add_rows_kernel<4, true>), dim3(blocks), dim3(256), 0, s, dst, ldd, src,
+                       lds, gate, ldg, rows, (int)width);
+  else if (vec)
+    hipLaunchKernelGGL((gate_add_rows_kernel<4, false>), dim3(blocks), dim3(256), 0, s, dst, ldd, src,
+                       lds, gate, ldg, rows, (int)width);
+  else if (add)
+    hipLaunchKernelGGL((gate_add_rows_kernel<1, true>), dim3(blocks), dim3(256), 0, s, dst, ldd, src,
+                       lds, gate, ldg, rows, (int)width);
   else
-    hipLaunchKernelGGL((gate_add_rows_kernel<1>), dim3(blocks), dim3(256), 0, s, dst, ldd, src, lds,
-                       gate, ldg, rows, (int)width);
+    hipLaunchKernelGGL((gate_add_rows_kernel<1, false>), dim3(blocks), dim3(256), 0, s, dst, ldd, src,
+                       lds, gate, ldg, rows, (int)width);
   INCAGG_HIP_TRY(hipGetLastError());
   return INCAGG_OK;
+}
+
+extern "C" int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds,
+                                        const float *gate, int64_t ldg, int64_t rows, int64_t width,
+                                        void *stream) {
+  return gate_rows(true, dst, ldd, src, lds, gate, ldg, rows, width, stream);
+}
+
+extern "C" int incagg_gate_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds,
+                                    const float *gate, int64_t ldg, int64_t rows, int64_t width,
+                                    void *stream) {
+  return gate_rows(false, dst, ldd, src, lds, gate, ldg, rows, width, stream);
 }
 
 extern "C" int incagg_rows_sum_f32(const float *const *srcs, const int64_t *lds, int64_t n_srcs,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "incagg_rows_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _i64, _i64, _int, _vp,
                                     _i64, _vp, _i64, _i64, _i64, _int, _int, _vp]),
     "incagg_gate_add_rows_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "incagg_gate_rows_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "incagg_gcn2_fold_weights_f32": (_int, [_vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     "incagg_gcn2_fold_weights_backward_f32": (_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "incagg_column_sums_ws_floats": (_i64, [_i64, _i64]),
@@ -92,7 +93,7 @@ class SpmmFuseStruct(_c.Structure):
 
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1}
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class AdamSegment(_c.Structure):

@@ -531,6 +531,24 @@ def gate_add_rows_(dst: Tensor, src: Tensor, gate: Tensor) -> Tensor:
     return dst
 
 
+def gate_rows(src: Tensor, gate: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """``where(gate > 0, src, 0)`` in one launch (incagg_gate_rows_f32): the backward of a relu
+    whose output (or input) is ``gate``.  ``out``: where to write, ``src`` itself allowed;
+    default a fresh matrix at the gather pitch."""
+    _need_cuda(src, "src")
+    if out is None:
+        out = rows_empty(src.size(0), src.size(1), src.device)
+    for t, name in ((out, "out"), (src, "src"), (gate, "gate")):
+        _rows_f32(t, name, src.device)
+    if src.shape != out.shape or gate.shape != out.shape:
+        raise ValueError("out, src and gate must have one shape")
+    with _on_device(src.device):
+        check(lib().incagg_gate_rows_f32(_ptr(out), _ld(out), _ptr(src), _ld(src), _ptr(gate),
+                                         _ld(gate), out.size(0), out.size(1),
+                                         _stream_of(src.device)))
+    return out
+
+
 def _fold_check(n_layers: int, c: int, betas) -> "ctypes.Array":
     if len(betas) != n_layers:
         raise ValueError("one beta per layer")

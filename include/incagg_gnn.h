@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define INCAGG_ABI_VERSION 7
+#define INCAGG_ABI_VERSION 8
 
 enum {
   INCAGG_OK = 0,
@@ -376,6 +376,12 @@ int incagg_rows_sum_f32(const float *const *srcs, const int64_t *lds, int64_t n_
 int incagg_gate_add_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds,
                              const float *gate, int64_t ldg, int64_t rows, int64_t width,
                              void *stream);
+/* dst[i, c] = gate[i, c] > 0 ? src[i, c] : 0 -- the backward of x.relu_() (every model's
+ * activation: models/gcn.py:146,182, models/gcn2.py:133,162, models/graphsage.py:192) on matrices
+ * with row pitches of their own; dst may be src.  (torch's kernel for pitched operands moves
+ * them at half the rate.) */
+int incagg_gate_rows_f32(float *dst, int64_t ldd, const float *src, int64_t lds, const float *gate,
+                         int64_t ldg, int64_t rows, int64_t width, void *stream);
 
 /* GCNII layers with separate weights (PyG's GCN2Conv as called at models/gcn2.py:46-48):
  *   out_l = (1 - alpha) (A x) ((1 - beta_l) I + beta_l W1_l) + alpha x_0 ((1 - beta_l) I + beta_l W2_l)

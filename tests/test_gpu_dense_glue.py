@@ -373,3 +373,27 @@ def test_batch_norm_rows_module_path_and_errors(ops):
         ops.batch_norm_forward(torch.randn(10, 6, device=dev), None, None, None, None, 0.1, 1e-5)
     with pytest.raises(ValueError):
         ops.batch_norm_forward(torch.randn(1, 8, device=dev), None, None, None, None, 0.1, 1e-5)
+
+
+@pytest.mark.parametrize("rows,width,pitches", [(16326, 256, (260, 288, 2080)), (5000, 41, (48, 48, 48)),
+                                                (333, 41, (41, 41, 41)), (1, 4, (4, 8, 4))])
+def test_gate_rows_is_the_relu_backward(ops, rows, width, pitches):
+    """incagg_gate_rows_f32 = torch's threshold_backward on matrices with three different row
+    pitches (bit-exact: a select), also in place over the incoming gradient; and through
+    nn.relu_into's autograd function."""
+    from torch_geometric_autoscale import nn as tnn
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(rows)
+    bufs = [torch.randn(rows, p, device=dev, generator=g) for p in pitches]
+    dy, h, out = (b[:, :width] for b in bufs)
+    want = torch.ops.aten.threshold_backward(dy, h, 0)
+    got = ops.gate_rows(dy, h, out=out)
+    assert got.data_ptr() == out.data_ptr() and torch.equal(got, want)
+    assert torch.equal(ops.gate_rows(dy, h), want)
+    dy2 = dy.clone()
+    assert torch.equal(ops.gate_rows(dy2, h, out=dy2), want)
+    if width % 4 == 0 or pitches[0] != width:
+        x = ops.rows_empty(rows, width, dev).copy_(h).requires_grad_(True)
+        y = tnn.relu_into(x * 1.0)
+        y.backward(dy)
+        assert torch.equal(x.grad, want)
