@@ -183,7 +183,8 @@ class _RowsLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        if dy.stride(-1) != 1:      # (rows with a pitch of their own go to the GEMMs as they are)
+            dy = dy.contiguous()
         dx = _mm_rows(dy, weight) if ctx.needs_input_grad[0] else None
         dw = _tn_product(dy, x) if ctx.needs_input_grad[1] else None
         db = _column_sums(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
@@ -748,7 +749,8 @@ class _SageUpdate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         agg, x_root, w_l, w_r = ctx.saved_tensors
-        dy = dy.contiguous()
+        if dy.stride(-1) != 1:
+            dy = dy.contiguous()
         need = ctx.needs_input_grad
         d_agg = _mm_rows(dy, w_l) if need[0] else None
         d_root = _mm_rows(dy, w_r) if need[1] else None
